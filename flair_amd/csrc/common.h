@@ -1,0 +1,110 @@
+// Shared device/host helpers for the FLAIR MI355X (gfx950) kernels.
+// Everything here is written for CDNA4 only: 64-wide wavefronts, MFMA, 160 KiB LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/flair_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+typedef uint16_t bf16_t;  // storage type of a bfloat16 element in HBM / LDS
+
+#define FLAIR_WAVE 64
+
+// ---- error plumbing (thread-local message, negative return codes) -------------
+void flair_set_error(const char* fmt, ...);
+#define FLAIR_CHECK(cond, ...)            \
+    do {                                  \
+        if (!(cond)) {                    \
+            flair_set_error(__VA_ARGS__); \
+            return FLAIR_ERR_ARG;         \
+        }                                 \
+    } while (0)
+#define FLAIR_LAUNCH_CHECK()                                                  \
+    do {                                                                      \
+        hipError_t e_ = hipGetLastError();                                    \
+        if (e_ != hipSuccess) {                                               \
+            flair_set_error("HIP launch failed: %s", hipGetErrorString(e_));  \
+            return FLAIR_ERR_HIP;                                             \
+        }                                                                     \
+    } while (0)
+
+// ---- bf16 <-> f32 --------------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t v) {
+    return __uint_as_float(((uint32_t)v) << 16);
+}
+// Plain cast: hipcc emits v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN preserving).
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+// Element traits: E = float or bf16_t.  VEC = elements per 16-byte access.
+template <typename E> struct ET;
+template <> struct ET<float> {
+    static constexpr int VEC = 4;
+    static constexpr int DT = FLAIR_F32;
+    static __device__ __forceinline__ float ld(const float* p) { return *p; }
+    static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct ET<bf16_t> {
+    static constexpr int VEC = 8;
+    static constexpr int DT = FLAIR_BF16;
+    static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+    static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+// 16-byte vector of elements <-> VEC floats
+template <typename E> struct Vec16;
+template <> struct Vec16<float> {
+    static __device__ __forceinline__ void load(const float* p, float* o) {
+        float4 v = *reinterpret_cast<const float4*>(p);
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    }
+    static __device__ __forceinline__ void store(float* p, const float* o) {
+        *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+};
+template <> struct Vec16<bf16_t> {
+    static __device__ __forceinline__ void load(const bf16_t* p, float* o) {
+        uint4 v = *reinterpret_cast<const uint4*>(p);
+        o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+        o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+        o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
+        o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, const float* o) {
+        uint4 v;
+        v.x = pack2bf(o[0], o[1]); v.y = pack2bf(o[2], o[3]);
+        v.z = pack2bf(o[4], o[5]); v.w = pack2bf(o[6], o[7]);
+        *reinterpret_cast<uint4*>(p) = v;
+    }
+};
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case FLAIR_ACT_RELU: return v > 0.f ? v : 0.f;
+        case FLAIR_ACT_LRELU01: return v > 0.f ? v : 0.1f * v;
+        case FLAIR_ACT_SILU: return silu_f(v);
+        default: return v;
+    }
+}
+
+// XCD-aware remap of a 1-D block id: blocks b and b+8 share an XCD (observed
+// round-robin dispatch), so give each XCD a contiguous chunk of the logical grid.
+// Bijective for any grid size (cdna_hip_programming.md section 5, "XCD swizzle").
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

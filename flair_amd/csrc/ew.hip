@@ -1,0 +1,267 @@
+// Streaming / small kernels around the UNet: layout conversion at the API edge,
+// timestep embedding, the f32 embedding linears and the fused sampler update.
+// All HBM- or launch-bound; 16-byte accesses on the NHWC side.
+#include "common.h"
+
+namespace {
+
+// ---- NCHW f32 (API edge) -> NHWC clip tensor, written at a channel offset ----------
+// One thread per (pixel, channel-of-source); reads are strided over channel planes but
+// each plane is contiguous over pixels (coalesced per channel), writes are 2/4-byte
+// scattered into a <= 64-byte pixel row: only used on 3..6-channel images.
+template <typename E>
+__global__ void nchw_to_nhwc_kernel(const float* src, int N, int C, long HW, E* dst, int ld, int coff) {
+    const long total = (long)N * HW;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long n = i / HW, p = i % HW;
+        for (int c = 0; c < C; ++c) ET<E>::st(dst + i * ld + coff + c, src[(n * C + c) * HW + p]);
+    }
+}
+
+template <typename E>
+__global__ void nhwc_to_nchw_kernel(const E* src, int ld, int coff, int N, int C, long HW, float* dst) {
+    const long total = (long)N * HW;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long n = i / HW, p = i % HW;
+        for (int c = 0; c < C; ++c) dst[(n * C + c) * HW + p] = ET<E>::ld(src + i * ld + coff + c);
+    }
+}
+
+// ---- sinusoidal embedding: out[n] = [cos(t*f_i) | sin(t*f_i)], f_i = P^(-i/half) ---
+__global__ void timestep_embedding_kernel(const float* t, int N, int dim, float maxPeriod, float* out) {
+    const int half = dim / 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * half) return;
+    const int n = i / half, k = i % half;
+    // same operation order as the reference: exp(-log(P) * k / half) in f32
+    const float freq = expf(-logf(maxPeriod) * (float)k / (float)half);
+    const float arg = t[n] * freq;
+    out[(long)n * dim + k] = cosf(arg);
+    out[(long)n * dim + half + k] = sinf(arg);
+    if ((dim & 1) && k == 0) out[(long)n * dim + dim - 1] = 0.f;
+}
+
+// ---- y[m][n] = act_out( sum_k act_in(x[m][k]) * w[n][k] + b[n] ), f32, M <= 32 -----
+// One wavefront per output feature: weights are read once, coalesced; the M input rows
+// live in LDS.  This is a GEMV-shaped, weight-bandwidth-bound op (M = frames of a clip).
+template <int MMAX>
+__global__ void linear_f32_kernel(const float* x, int M, int K, const float* w, const float* b, int N,
+                                  int actIn, int actOut, float* y, int yLd) {
+    extern __shared__ float xs[];  // [M][K]
+    for (int i = threadIdx.x; i < M * K; i += blockDim.x) xs[i] = apply_act(x[i], actIn);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float acc[MMAX];
+#pragma unroll
+    for (int m = 0; m < MMAX; ++m) acc[m] = 0.f;
+    const float* wr = w + (long)n * K;
+    for (int k = lane; k < K; k += 64) {
+        const float wv = wr[k];
+#pragma unroll
+        for (int m = 0; m < MMAX; ++m)
+            if (m < M) acc[m] = fmaf(xs[m * K + k], wv, acc[m]);
+    }
+#pragma unroll
+    for (int m = 0; m < MMAX; ++m) {
+        float v = acc[m];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0 && m < M) y[(long)m * yLd + n] = apply_act(v + (b ? b[n] : 0.f), actOut);
+    }
+}
+
+// ---- fused sampler update (gaussian_diffusion.py:325-327,465-470,507-515) ------------
+// phase 1: x0 = clamp(c_recip*x - c_recipm1*eps)                       (predict_xstart)
+// phase 2: x0 = clamp(x0 - gamma*restored); optional aux blend; then
+//          eps' = (c_recip*x - x0)/c_recipm1;  x_prev = c_prev*x0 + nz*co*(sqrt(1-rho)*eps' + sqrt(rho)*z)
+__global__ void predict_xstart_kernel(const float* x, const float* modelOut, int N, int C, int Cm, long HW,
+                                      float cRecip, float cRecipm1, int clip, float* x0) {
+    const long total = (long)N * C * HW;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long n = i / (C * HW), r = i % (C * HW);
+        const float eps = modelOut[n * Cm * HW + r];
+        float v = cRecip * x[i] - cRecipm1 * eps;
+        if (clip) v = fminf(fmaxf(v, -1.f), 1.f);
+        x0[i] = v;
+    }
+}
+
+__global__ void sampler_update_kernel(const float* x, float* x0, const float* restored, const float* aux,
+                                      const float* z, const float* prev, long frameElems, int T, int Tp,
+                                      long total, float gamma, float wAux, float cRecip,
+                                      float cRecipm1, float cPrev, float coNoise, float sq1mRho, float sqRho,
+                                      int clip, int nonzero, float* xPrev) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        float v = x0[i];
+        if (restored) {
+            v = v - gamma * restored[i];
+            if (clip) v = fminf(fmaxf(v, -1.f), 1.f);
+        }
+        if (aux) {
+            float f = aux[i];
+            if (clip) f = fminf(fmaxf(f, -1.f), 1.f);
+            v = wAux * v + (1.f - wAux) * f;
+        }
+        if (prev) {  // first Tp frames of every clip are pinned to the previous window's result
+            const long n = i / frameElems, r = i % frameElems;
+            const long b = n / T;
+            const int t = (int)(n % T);
+            if (t < Tp) v = prev[(b * Tp + t) * frameElems + r];
+        }
+        x0[i] = v;
+        const float xi = x[i];
+        const float eps = (cRecip * xi - v) / cRecipm1;
+        float out = cPrev * v;
+        if (nonzero) out += sq1mRho * coNoise * eps + sqRho * coNoise * z[i];
+        xPrev[i] = out;
+    }
+}
+
+// generic: out = a*x + b*y  (f32, flat)
+__global__ void axpby_kernel(const float* x, const float* y, float a, float b, long n, float* out) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = a * x[i] + (y ? b * y[i] : 0.f);
+}
+
+// per-pixel multiply of an NHWC tensor by a [pixels] f32 map (BasicVSR++ vsrpp_weights)
+template <typename E>
+__global__ void scale_pixels_kernel(E* x, int ld, int C, long P, const float* wmap) {
+    constexpr int VEC = ET<E>::VEC;
+    const int cv = C / VEC;
+    const long total = P * cv;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long p = i / cv;
+        const int c0 = (int)(i % cv) * VEC;
+        float v[VEC];
+        Vec16<E>::load(x + p * ld + c0, v);
+        const float s = wmap[p];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) v[k] *= s;
+        Vec16<E>::store(x + p * ld + c0, v);
+    }
+}
+
+inline int grid_for(long n, int block = 256, int cap = 2048) {
+    long g = (n + block - 1) / block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" int flair_nchw_f32_to_nhwc(const float* src, int N, int C, int H, int W, void* dst, int dtype,
+                                      int dst_ld, int dst_coff, hipStream_t stream) {
+    FLAIR_CHECK(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && dst_coff >= 0 && dst_coff + C <= dst_ld,
+                "flair_nchw_f32_to_nhwc: bad argument");
+    const long HW = (long)H * W;
+    if (dtype == FLAIR_BF16)
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(grid_for(N * HW)), dim3(256), 0, stream, src, N, C, HW,
+                           (bf16_t*)dst, dst_ld, dst_coff);
+    else if (dtype == FLAIR_F32)
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid_for(N * HW)), dim3(256), 0, stream, src, N, C, HW,
+                           (float*)dst, dst_ld, dst_coff);
+    else
+        FLAIR_CHECK(false, "flair_nchw_f32_to_nhwc: bad dtype");
+    FLAIR_LAUNCH_CHECK();
+    return FLAIR_OK;
+}
+
+extern "C" int flair_nhwc_to_nchw_f32(const void* src, int dtype, int src_ld, int src_coff, int N, int C, int H,
+                                      int W, float* dst, hipStream_t stream) {
+    FLAIR_CHECK(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && src_coff >= 0 && src_coff + C <= src_ld,
+                "flair_nhwc_to_nchw_f32: bad argument");
+    const long HW = (long)H * W;
+    if (dtype == FLAIR_BF16)
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(grid_for(N * HW)), dim3(256), 0, stream,
+                           (const bf16_t*)src, src_ld, src_coff, N, C, HW, dst);
+    else if (dtype == FLAIR_F32)
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(grid_for(N * HW)), dim3(256), 0, stream,
+                           (const float*)src, src_ld, src_coff, N, C, HW, dst);
+    else
+        FLAIR_CHECK(false, "flair_nhwc_to_nchw_f32: bad dtype");
+    FLAIR_LAUNCH_CHECK();
+    return FLAIR_OK;
+}
+
+extern "C" int flair_timestep_embedding(const float* t, int N, int dim, float max_period, float* out,
+                                        hipStream_t stream) {
+    FLAIR_CHECK(t && out && N > 0 && dim >= 2, "flair_timestep_embedding: bad argument");
+    const int n = N * (dim / 2);
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, t, N, dim, max_period,
+                       out);
+    FLAIR_LAUNCH_CHECK();
+    return FLAIR_OK;
+}
+
+extern "C" int flair_linear_f32(const float* x, int M, int K, const float* w, const float* bias, int N, int act_in,
+                                int act_out, float* y, int y_ld, hipStream_t stream) {
+    FLAIR_CHECK(x && w && y && M > 0 && M <= 32 && K > 0 && N > 0 && y_ld >= N, "flair_linear_f32: bad argument (M<=32)");
+    const size_t lds = (size_t)M * K * sizeof(float);
+    FLAIR_CHECK(lds <= 64 * 1024, "flair_linear_f32: M*K too large for LDS staging");
+    const int wavesPerBlock = 4;
+    const int grid = (N + wavesPerBlock - 1) / wavesPerBlock;
+    if (M <= 8)
+        hipLaunchKernelGGL(linear_f32_kernel<8>, dim3(grid), dim3(256), lds, stream, x, M, K, w, bias, N, act_in,
+                           act_out, y, y_ld);
+    else if (M <= 16)
+        hipLaunchKernelGGL(linear_f32_kernel<16>, dim3(grid), dim3(256), lds, stream, x, M, K, w, bias, N, act_in,
+                           act_out, y, y_ld);
+    else
+        hipLaunchKernelGGL(linear_f32_kernel<32>, dim3(grid), dim3(256), lds, stream, x, M, K, w, bias, N, act_in,
+                           act_out, y, y_ld);
+    FLAIR_LAUNCH_CHECK();
+    return FLAIR_OK;
+}
+
+extern "C" int flair_predict_xstart(const float* x, const float* model_out, int N, int C, int Cm, int H, int W,
+                                    float c_recip, float c_recipm1, int clip, float* x0, hipStream_t stream) {
+    FLAIR_CHECK(x && model_out && x0 && N > 0 && C > 0 && Cm >= C, "flair_predict_xstart: bad argument");
+    const long HW = (long)H * W;
+    hipLaunchKernelGGL(predict_xstart_kernel, dim3(grid_for((long)N * C * HW)), dim3(256), 0, stream, x, model_out, N,
+                       C, Cm, HW, c_recip, c_recipm1, clip, x0);
+    FLAIR_LAUNCH_CHECK();
+    return FLAIR_OK;
+}
+
+extern "C" int flair_sampler_update(const flair_sampler_coefs* c, const float* x, float* x0, const float* restored,
+                                    const float* aux, const float* z, const float* prev_recon, long n,
+                                    float* x_prev, hipStream_t stream) {
+    FLAIR_CHECK(c && x && x0 && x_prev && n > 0, "flair_sampler_update: null argument");
+    FLAIR_CHECK(!c->nonzero || z, "flair_sampler_update: noise required when t != 0");
+    FLAIR_CHECK(!prev_recon || (c->frame_elems > 0 && c->frames > 0 && c->prev_frames > 0 &&
+                                c->prev_frames <= c->frames && n % (c->frame_elems * c->frames) == 0),
+                "flair_sampler_update: prev_recon geometry");
+    hipLaunchKernelGGL(sampler_update_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, x0, restored, aux, z,
+                       prev_recon, (long)c->frame_elems, c->frames, c->prev_frames, n,
+                       c->gamma, c->w_aux, c->sqrt_recip_alphas_cumprod, c->sqrt_recipm1_alphas_cumprod,
+                       c->sqrt_alphas_cumprod_prev, c->sqrt_one_minus_alphas_cumprod_prev, c->sqrt_one_minus_rho,
+                       c->sqrt_rho, c->clip_denoised, c->nonzero, x_prev);
+    FLAIR_LAUNCH_CHECK();
+    return FLAIR_OK;
+}
+
+extern "C" int flair_axpby_f32(const float* x, const float* y, float a, float b, long n, float* out,
+                               hipStream_t stream) {
+    FLAIR_CHECK(x && out && n > 0, "flair_axpby_f32: bad argument");
+    hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, y, a, b, n, out);
+    FLAIR_LAUNCH_CHECK();
+    return FLAIR_OK;
+}
+
+extern "C" int flair_scale_pixels(void* x, int dtype, int ld, int C, long P, const float* wmap, hipStream_t stream) {
+    FLAIR_CHECK(x && wmap && P > 0 && C > 0, "flair_scale_pixels: bad argument");
+    if (dtype == FLAIR_BF16) {
+        FLAIR_CHECK(C % 8 == 0, "flair_scale_pixels: C %% 8");
+        hipLaunchKernelGGL(scale_pixels_kernel<bf16_t>, dim3(grid_for(P * (C / 8))), dim3(256), 0, stream,
+                           (bf16_t*)x, ld, C, P, wmap);
+    } else {
+        FLAIR_CHECK(C % 4 == 0, "flair_scale_pixels: C %% 4");
+        hipLaunchKernelGGL(scale_pixels_kernel<float>, dim3(grid_for(P * (C / 4))), dim3(256), 0, stream, (float*)x,
+                           ld, C, P, wmap);
+    }
+    FLAIR_LAUNCH_CHECK();
+    return FLAIR_OK;
+}

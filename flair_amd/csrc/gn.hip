@@ -1,0 +1,315 @@
+// GroupNorm(32 groups) over a whole clip + fused affine/FiLM + SiLU (+ 2x resample).
+//
+// Replaces GroupNorm32 behind LazyReshaper3D (guided_diffusion/nn_new.py:17-19,
+// nn.py:359-367) as used by ResBlock.in_layers/out_layers (unet_new.py:237-278,
+// 309-329: SiLU, (1+scale)*norm+shift, Upsample/Downsample h_upd/x_upd), the
+// attention norms (:358,:408,:461) and the output head (:1216-1222).
+//
+// Statistics are joint over (C/groups) x frames_per_stat x H x W.  HBM-bound: three
+// launches per norm, two passes over the tensor:
+//   gn_partial  : every workgroup streams a pixel range with 16-byte loads, keeps
+//                 per-channel f32 sum / sum-of-squares in registers, folds the rows
+//                 of the workgroup through LDS and writes one partial per channel;
+//   gn_finalize : one wavefront per (stat, group) adds the partials in f64 with a
+//                 64-lane shuffle tree -> mean, rstd;
+//   gn_apply    : y = act(x*A + B) with A,B folded per (frame, channel) from
+//                 mean/rstd/gamma/beta/(scale,shift); optionally writes the 2x2
+//                 average-pooled or nearest-upsampled result and the resampled
+//                 raw input in the same pass.
+#include "common.h"
+
+namespace {
+
+struct GnSrc {
+    const void* x[2];
+    int c[2];   // channels per segment (sum = C)
+    int ld[2];  // pixel stride per segment
+};
+
+template <typename E>
+__global__ void gn_partial_kernel(GnSrc s, int C, long pixPerStat, int blocksPerStat, float* part) {
+    constexpr int VEC = ET<E>::VEC;
+    extern __shared__ float red[];  // [2][rows][C]
+    const int cv = C / VEC;
+    const int rows = blockDim.x / cv;
+    const int slot = threadIdx.x % cv, r = threadIdx.x / cv;
+    const int stat = blockIdx.x / blocksPerStat, blk = blockIdx.x % blocksPerStat;
+    const long per = (pixPerStat + blocksPerStat - 1) / blocksPerStat;
+    const long beg = stat * pixPerStat + (long)blk * per;
+    long end = beg + per;
+    const long lim = (stat + 1) * pixPerStat;
+    if (end > lim) end = lim;
+
+    int c0 = slot * VEC;
+    const E* base;
+    int ld;
+    if (c0 < s.c[0]) {
+        base = reinterpret_cast<const E*>(s.x[0]) + c0;
+        ld = s.ld[0];
+    } else {
+        base = reinterpret_cast<const E*>(s.x[1]) + (c0 - s.c[0]);
+        ld = s.ld[1];
+    }
+    float sum[VEC], sq[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) sum[i] = sq[i] = 0.f;
+#pragma unroll 4
+    for (long p = beg + r; p < end; p += rows) {
+        float v[VEC];
+        Vec16<E>::load(base + p * ld, v);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            sum[i] += v[i];
+            sq[i] = fmaf(v[i], v[i], sq[i]);
+        }
+    }
+    float* rs = red;
+    float* rq = red + rows * C;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        rs[r * C + c0 + i] = sum[i];
+        rq[r * C + c0 + i] = sq[i];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float a = 0.f, b = 0.f;
+        for (int k = 0; k < rows; ++k) {
+            a += rs[k * C + c];
+            b += rq[k * C + c];
+        }
+        part[((long)blockIdx.x * 2 + 0) * C + c] = a;
+        part[((long)blockIdx.x * 2 + 1) * C + c] = b;
+    }
+}
+
+// one wave per (stat, group)
+__global__ void gn_finalize_kernel(const float* part, int C, int groups, int blocksPerStat,
+                                   long pixPerStat, float eps, float* stats) {
+    const int lane = threadIdx.x & 63;
+    const int sg = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int stat = sg / groups, g = sg % groups;
+    const int cpg = C / groups;
+    double a = 0.0, b = 0.0;
+    const int n = blocksPerStat * cpg;
+    for (int i = lane; i < n; i += 64) {
+        const int blk = i / cpg, c = g * cpg + i % cpg;
+        const long o = ((long)(stat * blocksPerStat + blk) * 2) * C + c;
+        a += (double)part[o];
+        b += (double)part[o + C];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_xor(a, off);
+        b += __shfl_xor(b, off);
+    }
+    if (lane == 0) {
+        const double cnt = (double)pixPerStat * cpg;
+        const double mean = a / cnt;
+        double var = b / cnt - mean * mean;
+        if (var < 0) var = 0;
+        stats[sg * 2 + 0] = (float)mean;
+        stats[sg * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+struct GnApply {
+    GnSrc s;
+    int C, groups;
+    int F, H, W;           // frames, input frame size
+    int framesPerStat;
+    const float* stats;    // [nstat][groups][2]
+    const float* gamma;    // [C]
+    const float* beta;     // [C]
+    const float* film;     // [F][filmLd] rows of (scale[C] | shift[C]) or null
+    int filmLd;
+    int act;
+    int resample;          // 0 none, 1 avg-pool 2x2, 2 nearest x2
+    void* y;  int yLd;     // activated (and resampled) output
+    void* raw; int rawLd;  // optional: resampled un-normalised input
+    int blocksPerFrame;
+};
+
+template <typename E>
+__global__ void gn_apply_kernel(GnApply a) {
+    constexpr int VEC = ET<E>::VEC;
+    const int cv = a.C / VEC;
+    const int rows = blockDim.x / cv;
+    const int slot = threadIdx.x % cv, r = threadIdx.x / cv;
+    const int f = blockIdx.x / a.blocksPerFrame, blk = blockIdx.x % a.blocksPerFrame;
+    const int c0 = slot * VEC;
+    const E* base;
+    int ld;
+    if (c0 < a.s.c[0]) {
+        base = reinterpret_cast<const E*>(a.s.x[0]) + c0;
+        ld = a.s.ld[0];
+    } else {
+        base = reinterpret_cast<const E*>(a.s.x[1]) + (c0 - a.s.c[0]);
+        ld = a.s.ld[1];
+    }
+    // fold normalisation + affine + FiLM into y = x*A + B
+    float A[VEC], B[VEC];
+    const int cpg = a.C / a.groups;
+    const int stat = f / a.framesPerStat;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        const int c = c0 + i;
+        const int g = c / cpg;
+        const float mean = a.stats[(stat * a.groups + g) * 2], rstd = a.stats[(stat * a.groups + g) * 2 + 1];
+        float ga = a.gamma[c] * rstd;
+        float be = a.beta[c] - mean * ga;
+        if (a.film) {
+            const float sc = 1.f + a.film[(long)f * a.filmLd + c];
+            const float sh = a.film[(long)f * a.filmLd + a.C + c];
+            ga *= sc;
+            be = be * sc + sh;
+        }
+        A[i] = ga;
+        B[i] = be;
+    }
+    E* y = reinterpret_cast<E*>(a.y);
+    E* raw = reinterpret_cast<E*>(a.raw);
+    const long fin = (long)f * a.H * a.W;
+    if (a.resample == 0) {
+        const long n = (long)a.H * a.W;
+        const long per = (n + a.blocksPerFrame - 1) / a.blocksPerFrame;
+        long end = (blk + 1) * per;
+        if (end > n) end = n;
+        for (long p = blk * per + r; p < end; p += rows) {
+            float v[VEC];
+            Vec16<E>::load(base + (fin + p) * ld, v);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) v[i] = apply_act(fmaf(v[i], A[i], B[i]), a.act);
+            Vec16<E>::store(y + (fin + p) * a.yLd + c0, v);
+        }
+    } else if (a.resample == 1) {
+        const int Ho = a.H / 2, Wo = a.W / 2;
+        const long n = (long)Ho * Wo;
+        const long per = (n + a.blocksPerFrame - 1) / a.blocksPerFrame;
+        long end = (blk + 1) * per;
+        if (end > n) end = n;
+        const long fout = (long)f * n;
+        for (long p = blk * per + r; p < end; p += rows) {
+            const int ho = (int)(p / Wo), wo = (int)(p % Wo);
+            float accv[VEC], accr[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) accv[i] = accr[i] = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const long pi = fin + (long)(2 * ho + (q >> 1)) * a.W + 2 * wo + (q & 1);
+                float v[VEC];
+                Vec16<E>::load(base + pi * ld, v);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    accr[i] += v[i];
+                    accv[i] += apply_act(fmaf(v[i], A[i], B[i]), a.act);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                accv[i] *= 0.25f;
+                accr[i] *= 0.25f;
+            }
+            Vec16<E>::store(y + (fout + p) * a.yLd + c0, accv);
+            if (raw) Vec16<E>::store(raw + (fout + p) * a.rawLd + c0, accr);
+        }
+    } else {
+        const long n = (long)a.H * a.W;
+        const long per = (n + a.blocksPerFrame - 1) / a.blocksPerFrame;
+        long end = (blk + 1) * per;
+        if (end > n) end = n;
+        const int Wo = a.W * 2;
+        const long fout = (long)f * n * 4;
+        for (long p = blk * per + r; p < end; p += rows) {
+            const int h = (int)(p / a.W), w = (int)(p % a.W);
+            float v[VEC], u[VEC];
+            Vec16<E>::load(base + (fin + p) * ld, u);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) v[i] = apply_act(fmaf(u[i], A[i], B[i]), a.act);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const long po = fout + (long)(2 * h + (q >> 1)) * Wo + 2 * w + (q & 1);
+                Vec16<E>::store(y + po * a.yLd + c0, v);
+                if (raw) Vec16<E>::store(raw + po * a.rawLd + c0, u);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" size_t flair_groupnorm_workspace_bytes(const flair_gn_params* p) {
+    if (!p) return 0;
+    const int nstat = p->F / p->frames_per_stat;
+    const long pix = (long)p->frames_per_stat * p->H * p->W;
+    int bps = (int)((pix + 255) / 256);
+    if (bps > 1024) bps = 1024;
+    if (bps < 1) bps = 1;
+    // partials [nstat*bps][2][C] + stats [nstat][groups][2]
+    return ((size_t)nstat * bps * 2 * p->C + (size_t)nstat * p->groups * 2) * sizeof(float);
+}
+
+extern "C" int flair_groupnorm_nhwc(const flair_gn_params* p, const void* x0, const void* x1,
+                                    const float* gamma, const float* beta, const float* film,
+                                    void* y, void* raw, void* workspace, hipStream_t stream) {
+    FLAIR_CHECK(p && x0 && gamma && beta && y && workspace, "flair_groupnorm_nhwc: null argument");
+    FLAIR_CHECK(p->dtype == FLAIR_F32 || p->dtype == FLAIR_BF16, "flair_groupnorm_nhwc: bad dtype");
+    const int vec = p->dtype == FLAIR_BF16 ? 8 : 4;
+    const int C = p->C;
+    FLAIR_CHECK(C > 0 && C % vec == 0 && C % p->groups == 0, "flair_groupnorm_nhwc: C=%d groups=%d", C, p->groups);
+    FLAIR_CHECK(p->c0 > 0 && p->c0 <= C && p->c0 % vec == 0 && (p->c0 == C || x1),
+                "flair_groupnorm_nhwc: bad segment split c0=%d", p->c0);
+    FLAIR_CHECK(p->F > 0 && p->frames_per_stat > 0 && p->F % p->frames_per_stat == 0,
+                "flair_groupnorm_nhwc: frames %d / frames_per_stat %d", p->F, p->frames_per_stat);
+    FLAIR_CHECK(p->resample >= 0 && p->resample <= 2, "flair_groupnorm_nhwc: resample mode");
+    FLAIR_CHECK(p->resample != 1 || (p->H % 2 == 0 && p->W % 2 == 0), "flair_groupnorm_nhwc: odd size for pooling");
+    const int cv = C / vec;
+    FLAIR_CHECK(cv <= 256, "flair_groupnorm_nhwc: C=%d too wide", C);
+    const int rows = 256 / cv;
+    const int threads = rows * cv;
+    const int nstat = p->F / p->frames_per_stat;
+    const long pix = (long)p->frames_per_stat * p->H * p->W;
+    int bps = (int)((pix + 255) / 256);
+    if (bps > 1024) bps = 1024;
+    if (bps < 1) bps = 1;
+    FLAIR_CHECK(!film || p->film_ld >= 2 * C, "flair_groupnorm_nhwc: film_ld");
+    float* part = reinterpret_cast<float*>(workspace);
+    float* stats = part + (size_t)nstat * bps * 2 * C;
+
+    GnSrc s;
+    s.x[0] = x0; s.x[1] = x1;
+    s.c[0] = p->c0; s.c[1] = C - p->c0;
+    s.ld[0] = p->ld0; s.ld[1] = p->ld1;
+    const size_t lds = (size_t)2 * rows * C * sizeof(float);
+    if (p->dtype == FLAIR_BF16)
+        hipLaunchKernelGGL(gn_partial_kernel<bf16_t>, dim3(nstat * bps), dim3(threads), lds, stream, s, C, pix, bps, part);
+    else
+        hipLaunchKernelGGL(gn_partial_kernel<float>, dim3(nstat * bps), dim3(threads), lds, stream, s, C, pix, bps, part);
+    FLAIR_LAUNCH_CHECK();
+    const int sg = nstat * p->groups;
+    FLAIR_CHECK(sg % 4 == 0 || sg < 4, "flair_groupnorm_nhwc: groups");
+    const int wavesPerBlock = sg >= 4 ? 4 : sg;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(sg / wavesPerBlock), dim3(64 * wavesPerBlock), 0, stream,
+                       part, C, p->groups, bps, pix, p->eps, stats);
+    FLAIR_LAUNCH_CHECK();
+
+    GnApply a;
+    a.s = s;
+    a.C = C; a.groups = p->groups;
+    a.F = p->F; a.H = p->H; a.W = p->W;
+    a.framesPerStat = p->frames_per_stat;
+    a.stats = stats; a.gamma = gamma; a.beta = beta; a.film = film; a.filmLd = p->film_ld;
+    a.act = p->act; a.resample = p->resample;
+    a.y = y; a.yLd = p->y_ld; a.raw = raw; a.rawLd = p->raw_ld;
+    const long outPix = p->resample == 1 ? (long)p->H * p->W / 4 : (long)p->H * p->W;
+    int bpf = (int)((outPix + (long)rows * 8 - 1) / ((long)rows * 8));
+    const int maxBpf = 4096 / p->F > 0 ? 4096 / p->F : 1;
+    if (bpf > maxBpf) bpf = maxBpf;
+    if (bpf < 1) bpf = 1;
+    a.blocksPerFrame = bpf;
+    if (p->dtype == FLAIR_BF16)
+        hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3(p->F * bpf), dim3(threads), 0, stream, a);
+    else
+        hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(p->F * bpf), dim3(threads), 0, stream, a);
+    FLAIR_LAUNCH_CHECK();
+    return FLAIR_OK;
+}

@@ -1,0 +1,209 @@
+// Bilinear resampling kernels on NHWC clips.
+//
+//  * flair_flow_warp      -- mmedit flow_warp = F.grid_sample(bilinear, align_corners=True,
+//                            zeros|border) on pixel coordinates + flow; call sites
+//                            guided_diffusion/unet_new.py:706,718,719 (BasicVSR++ propagation)
+//                            and SPyNet's per-level warp.
+//  * flair_flow_compose   -- flow_n2 = flow_n1 + warp(flow_n2, flow_n1) (unet_new.py:716-718)
+//                            on 2-channel f32 flow fields.
+//  * flair_resize_nhwc    -- F.interpolate bilinear (align_corners 0/1) / bicubic
+//                            (align_corners=False, A=-0.75) / avg_pool2d 2x2 used by SPyNet's
+//                            pyramid and by the flow-input resize (unet_new.py:1336-1345).
+// All are gather-bound: one thread per (output pixel, 16-byte channel chunk).
+#include "common.h"
+
+namespace {
+
+// PyTorch's grid_sample round trip: pixel -> [-1,1] -> pixel (align_corners=True).
+__device__ __forceinline__ float gs_coord(float pix, int size) {
+    const float denom = (float)(size > 1 ? size - 1 : 1);
+    const float g = 2.0f * pix / denom - 1.0f;
+    return ((g + 1.f) / 2.f) * (float)(size - 1);
+}
+
+template <typename E>
+__global__ void flow_warp_kernel(const E* x, int xLd, const float* flow, int F, int H, int W, int C, int border,
+                                 E* y, int yLd) {
+    constexpr int VEC = ET<E>::VEC;
+    const int cv = C / VEC;
+    const long total = (long)F * H * W * cv;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % cv) * VEC;
+        const long p = i / cv;
+        const int w = (int)(p % W);
+        const int h = (int)((p / W) % H);
+        const long f = p / ((long)W * H);
+        const float2 fl = *reinterpret_cast<const float2*>(flow + p * 2);
+        float ix = gs_coord((float)w + fl.x, W);
+        float iy = gs_coord((float)h + fl.y, H);
+        if (border) {
+            ix = fminf(fmaxf(ix, 0.f), (float)(W - 1));
+            iy = fminf(fmaxf(iy, 0.f), (float)(H - 1));
+        }
+        const float fx = floorf(ix), fy = floorf(iy);
+        const int x0 = (int)fx, y0 = (int)fy;
+        const float ax = ix - fx, ay = iy - fy;
+        const float wgt[4] = {(1.f - ax) * (1.f - ay), ax * (1.f - ay), (1.f - ax) * ay, ax * ay};
+        float acc[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+        const E* fb = x + f * H * W * xLd + c0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int xx = x0 + (q & 1), yy = y0 + (q >> 1);
+            if ((unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H) {
+                float v[VEC];
+                Vec16<E>::load(fb + ((long)yy * W + xx) * xLd, v);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[k] = fmaf(wgt[q], v[k], acc[k]);
+            }
+        }
+        Vec16<E>::store(y + p * yLd + c0, acc);
+    }
+}
+
+// out = f1 + warp(f2, f1), zeros padding; flows are [F][H][W][2] f32
+__global__ void flow_compose_kernel(const float* f1, const float* f2, int F, int H, int W, float* out) {
+    const long total = (long)F * H * W;
+    for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
+        const int w = (int)(p % W);
+        const int h = (int)((p / W) % H);
+        const long f = p / ((long)W * H);
+        const float2 fl = *reinterpret_cast<const float2*>(f1 + p * 2);
+        const float ix = gs_coord((float)w + fl.x, W), iy = gs_coord((float)h + fl.y, H);
+        const float fx = floorf(ix), fy = floorf(iy);
+        const int x0 = (int)fx, y0 = (int)fy;
+        const float ax = ix - fx, ay = iy - fy;
+        const float wgt[4] = {(1.f - ax) * (1.f - ay), ax * (1.f - ay), (1.f - ax) * ay, ax * ay};
+        float ox = 0.f, oy = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int xx = x0 + (q & 1), yy = y0 + (q >> 1);
+            if ((unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H) {
+                const float2 v = *reinterpret_cast<const float2*>(f2 + ((f * H + yy) * W + xx) * 2);
+                ox = fmaf(wgt[q], v.x, ox);
+                oy = fmaf(wgt[q], v.y, oy);
+            }
+        }
+        *reinterpret_cast<float2*>(out + p * 2) = make_float2(fl.x + ox, fl.y + oy);
+    }
+}
+
+// ---- generic scalar-channel resize (few channels: images and flows) ------------------
+__device__ __forceinline__ float cubic1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
+__device__ __forceinline__ float cubic2(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
+
+// mode: 0 bilinear align_corners=False, 1 bilinear align_corners=True, 2 bicubic
+// (align_corners=False, A=-0.75, border-clamped taps), 3 2x2 average pool.
+template <typename E>
+__global__ void resize_kernel(const E* x, int xLd, int F, int Hi, int Wi, int C, int mode, int Ho, int Wo, E* y,
+                              int yLd, float outScaleX, float outScaleY) {
+    const long total = (long)F * Ho * Wo * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long p = i / C;
+        const int wo = (int)(p % Wo);
+        const int ho = (int)((p / Wo) % Ho);
+        const long f = p / ((long)Wo * Ho);
+        const E* fb = x + f * Hi * Wi * xLd + c;
+        float r = 0.f;
+        if (mode == 3) {
+            for (int q = 0; q < 4; ++q)
+                r += ET<E>::ld(fb + ((long)(2 * ho + (q >> 1)) * Wi + 2 * wo + (q & 1)) * xLd);
+            r *= 0.25f;
+        } else if (mode == 2) {
+            const float sx = (float)Wi / (float)Wo, sy = (float)Hi / (float)Ho;
+            const float rx = sx * ((float)wo + 0.5f) - 0.5f, ry = sy * ((float)ho + 0.5f) - 0.5f;
+            const float fx = floorf(rx), fy = floorf(ry);
+            const float tx = rx - fx, ty = ry - fy;
+            const float A = -0.75f;
+            const float cx[4] = {cubic2(tx + 1.f, A), cubic1(tx, A), cubic1(1.f - tx, A), cubic2(2.f - tx, A)};
+            const float cy[4] = {cubic2(ty + 1.f, A), cubic1(ty, A), cubic1(1.f - ty, A), cubic2(2.f - ty, A)};
+            for (int j = 0; j < 4; ++j) {
+                int yy = (int)fy - 1 + j;
+                yy = yy < 0 ? 0 : (yy > Hi - 1 ? Hi - 1 : yy);
+                float rowv = 0.f;
+                for (int k = 0; k < 4; ++k) {
+                    int xx = (int)fx - 1 + k;
+                    xx = xx < 0 ? 0 : (xx > Wi - 1 ? Wi - 1 : xx);
+                    rowv += cx[k] * ET<E>::ld(fb + ((long)yy * Wi + xx) * xLd);
+                }
+                r += cy[j] * rowv;
+            }
+        } else {
+            float rx, ry;
+            if (mode == 1) {
+                const float sx = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+                const float sy = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f;
+                rx = sx * (float)wo;
+                ry = sy * (float)ho;
+            } else {
+                const float sx = (float)Wi / (float)Wo, sy = (float)Hi / (float)Ho;
+                rx = fmaxf(sx * ((float)wo + 0.5f) - 0.5f, 0.f);
+                ry = fmaxf(sy * ((float)ho + 0.5f) - 0.5f, 0.f);
+            }
+            const int x0 = (int)rx, y0 = (int)ry;
+            const int x1 = x0 + (x0 < Wi - 1 ? 1 : 0), y1 = y0 + (y0 < Hi - 1 ? 1 : 0);
+            const float ax = rx - (float)x0, ay = ry - (float)y0;
+            const float v00 = ET<E>::ld(fb + ((long)y0 * Wi + x0) * xLd), v01 = ET<E>::ld(fb + ((long)y0 * Wi + x1) * xLd);
+            const float v10 = ET<E>::ld(fb + ((long)y1 * Wi + x0) * xLd), v11 = ET<E>::ld(fb + ((long)y1 * Wi + x1) * xLd);
+            r = (1.f - ay) * ((1.f - ax) * v00 + ax * v01) + ay * ((1.f - ax) * v10 + ax * v11);
+        }
+        r *= (c == 0 ? outScaleX : (c == 1 ? outScaleY : 1.f));
+        ET<E>::st(y + p * yLd + c, r);
+    }
+}
+
+inline int grid_for(long n) {
+    long g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" int flair_flow_warp(const void* x, int dtype, int x_ld, const float* flow, int F, int H, int W, int C,
+                               int border, void* y, int y_ld, hipStream_t stream) {
+    FLAIR_CHECK(x && flow && y && F > 0 && H > 0 && W > 0 && C > 0, "flair_flow_warp: bad argument");
+    if (dtype == FLAIR_BF16) {
+        FLAIR_CHECK(C % 8 == 0 && x_ld % 8 == 0 && y_ld % 8 == 0, "flair_flow_warp: bf16 needs C %% 8 == 0");
+        hipLaunchKernelGGL(flow_warp_kernel<bf16_t>, dim3(grid_for((long)F * H * W * (C / 8))), dim3(256), 0, stream,
+                           (const bf16_t*)x, x_ld, flow, F, H, W, C, border, (bf16_t*)y, y_ld);
+    } else if (dtype == FLAIR_F32) {
+        FLAIR_CHECK(C % 4 == 0 && x_ld % 4 == 0 && y_ld % 4 == 0, "flair_flow_warp: f32 needs C %% 4 == 0");
+        hipLaunchKernelGGL(flow_warp_kernel<float>, dim3(grid_for((long)F * H * W * (C / 4))), dim3(256), 0, stream,
+                           (const float*)x, x_ld, flow, F, H, W, C, border, (float*)y, y_ld);
+    } else {
+        FLAIR_CHECK(false, "flair_flow_warp: bad dtype");
+    }
+    FLAIR_LAUNCH_CHECK();
+    return FLAIR_OK;
+}
+
+extern "C" int flair_flow_compose(const float* f1, const float* f2, int F, int H, int W, float* out,
+                                  hipStream_t stream) {
+    FLAIR_CHECK(f1 && f2 && out && F > 0 && H > 0 && W > 0, "flair_flow_compose: bad argument");
+    hipLaunchKernelGGL(flow_compose_kernel, dim3(grid_for((long)F * H * W)), dim3(256), 0, stream, f1, f2, F, H, W,
+                       out);
+    FLAIR_LAUNCH_CHECK();
+    return FLAIR_OK;
+}
+
+extern "C" int flair_resize_nhwc(const void* x, int dtype, int x_ld, int F, int Hi, int Wi, int C, int mode, int Ho,
+                                 int Wo, void* y, int y_ld, float scale_c0, float scale_c1, hipStream_t stream) {
+    FLAIR_CHECK(x && y && F > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0 && mode >= 0 && mode <= 3,
+                "flair_resize_nhwc: bad argument");
+    FLAIR_CHECK(mode != 3 || (Hi == 2 * Ho && Wi == 2 * Wo), "flair_resize_nhwc: avg-pool needs exact 2x");
+    const long n = (long)F * Ho * Wo * C;
+    if (dtype == FLAIR_BF16)
+        hipLaunchKernelGGL(resize_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, stream, (const bf16_t*)x, x_ld, F,
+                           Hi, Wi, C, mode, Ho, Wo, (bf16_t*)y, y_ld, scale_c0, scale_c1);
+    else if (dtype == FLAIR_F32)
+        hipLaunchKernelGGL(resize_kernel<float>, dim3(grid_for(n)), dim3(256), 0, stream, (const float*)x, x_ld, F,
+                           Hi, Wi, C, mode, Ho, Wo, (float*)y, y_ld, scale_c0, scale_c1);
+    else
+        FLAIR_CHECK(false, "flair_resize_nhwc: bad dtype");
+    FLAIR_LAUNCH_CHECK();
+    return FLAIR_OK;
+}

@@ -1,0 +1,228 @@
+/* libflair_hip.so -- C ABI of the MI355X (gfx950) kernels behind FLAIR's sampling hot path.
+ *
+ * Drop-in boundary.  The reference has no FFI on this path: its
+ * Python calls ATen / torchvision / flash-attn / mmcv operators.  Each entry point below
+ * names the reference call site(s) it replaces (paths relative to the reference root,
+ * guided_diffusion/...).  The only native precedent in the reference is the pybind
+ * module dcn/src/deform_conv_ext.cpp:150-163, whose conventions are kept: the caller owns
+ * and pre-allocates every buffer, inputs are contiguous, work is enqueued on the caller's
+ * stream, and nothing synchronises with the host.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers;
+ *   - every function returns FLAIR_OK (0) or a negative flair_status and records a
+ *     message retrievable with flair_last_error() (thread-local);
+ *   - functions are asynchronous on `stream`, re-entrant, allocate nothing, and may be
+ *     captured into a hipGraph;
+ *   - activations are "clip tensors": [T][H][W][C] with C innermost ("NHWC"), element
+ *     type FLAIR_F32 or FLAIR_BF16; per-channel parameters (bias, norm scale) are f32;
+ *   - `ld` arguments are the element distance between consecutive pixels, so a tensor
+ *     may be a channel slice of a wider buffer (this is how torch.cat is avoided).
+ */
+#ifndef FLAIR_HIP_H
+#define FLAIR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef __HIP_PLATFORM_AMD__
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+typedef enum {
+    FLAIR_OK = 0,
+    FLAIR_ERR_ARG = -1, /* bad shape / alignment / null pointer */
+    FLAIR_ERR_HIP = -2  /* HIP runtime refused the launch */
+} flair_status;
+
+typedef enum { FLAIR_F32 = 0, FLAIR_BF16 = 1 } flair_dtype;
+
+typedef enum {
+    FLAIR_ACT_NONE = 0,
+    FLAIR_ACT_RELU = 1,
+    FLAIR_ACT_LRELU01 = 2, /* LeakyReLU(0.1) */
+    FLAIR_ACT_SILU = 3
+} flair_act;
+
+/* Last error message of the calling thread ("" if none). */
+const char* flair_last_error(void);
+/* ABI version of this header (bumped on incompatible change). */
+int flair_abi_version(void);
+
+/* ------------------------------------------------------------------ convolution
+ * Y = act(conv(X, W) + bias) + res0 + res1, times out_scale.  "same" zero padding,
+ * stride 1, odd kernel sizes; KT > 1 convolves across frames (Conv3d), KT == 1 treats
+ * frames as a batch (Conv2d / Conv1d-1x1 / Linear on pixels).
+ * Replaces: unet_new.py:240-295 (ResBlock conv_nd 2-D/3-D, 1x1 skip), :359,:367,:409,:417
+ * (qkv / proj_out Conv1d), :455-459 (TemporalAttention linears/proj), :659-668
+ * (ResidualBlocksWithInputConv trunks, conv_last), :859-867 (offset conv stack), :993,
+ * :1220 (stem / head convs); mmedit SPyNet 7x7 convs (unet_new.py:985).
+ *   x[i]   : input segment i, [T][H][W] pixels of seg_c[i] channels, pixel stride seg_ld[i];
+ *            the segments are the channel-wise concatenation the reference builds with
+ *            th.cat (seg_c[i] must be a multiple of 32 (bf16) / 16 (f32); pad with zeros)
+ *   w      : [Cout][KT*KH*KW][sum seg_c] in the activation dtype
+ *   bias   : [Cout] f32 or NULL;  res0/res1: [T][H][W][Cout-slice] or NULL
+ *   y      : [T][H][W] pixels, y_ld elements apart, Cout (multiple of 4) written per pixel */
+typedef struct {
+    int dtype;
+    int T, H, W;
+    int KT, KH, KW;
+    int Cout;
+    int nseg;
+    int seg_c[4];
+    int seg_ld[4];
+    int y_ld;
+    int res_ld[2];
+    int act;
+    float out_scale;
+} flair_conv_params;
+
+int flair_conv_nhwc(const flair_conv_params* p, const void* const* x, const void* w,
+                    const float* bias, const void* res0, const void* res1, void* y,
+                    hipStream_t stream);
+
+
+/* ------------------------------------------------------- GroupNorm + SiLU (+ FiLM)
+ * y = act( GroupNorm(x) * (1 + scale) + shift ), statistics joint over
+ * (C/groups) x frames_per_stat x H x W (frames_per_stat = T for the FLAIR video UNet,
+ * 1 for per-frame norms).  The input may be the channel concatenation of two stored
+ * tensors (x0: first c0 channels, x1: the remaining C - c0).  resample: 0 none,
+ * 1 = 2x2 average pooling of the activated result, 2 = nearest 2x upsampling; `raw`
+ * (optional) receives the identically resampled un-normalised input.
+ * Replaces: nn_new.py:17-19 GroupNorm32 behind nn.py:359-367 LazyReshaper3D, with the
+ * SiLU / (1+scale)*h+shift / Upsample / Downsample steps of unet_new.py:237-329, the
+ * attention norms (:358,:408,:461) and the head (:1216-1222).
+ *   gamma, beta : [C] f32;  film : [F][film_ld] f32 rows of (scale[C] | shift[C]) or NULL
+ *   workspace   : flair_groupnorm_workspace_bytes(p) bytes of device scratch */
+typedef struct {
+    int dtype;
+    int C, c0;   /* channels in total / in segment 0 */
+    int ld0, ld1;
+    int groups;
+    int F, H, W;
+    int frames_per_stat;
+    float eps;
+    int act;
+    int resample;
+    int y_ld, raw_ld;
+    int film_ld;
+} flair_gn_params;
+
+size_t flair_groupnorm_workspace_bytes(const flair_gn_params* p);
+int flair_groupnorm_nhwc(const flair_gn_params* p, const void* x0, const void* x1,
+                         const float* gamma, const float* beta, const float* film, void* y,
+                         void* raw, void* workspace, hipStream_t stream);
+
+/* ----------------------------------------------------------------- API-edge layout
+ * (N,C,H,W) f32 <-> channel slice [coff, coff+C) of an NHWC clip tensor.  Replaces the
+ * rearrange/cat/type casts at unet_new.py:1330-1331,1353,1361-1362. */
+int flair_nchw_f32_to_nhwc(const float* src, int N, int C, int H, int W, void* dst, int dtype,
+                           int dst_ld, int dst_coff, hipStream_t stream);
+int flair_nhwc_to_nchw_f32(const void* src, int dtype, int src_ld, int src_coff, int N, int C,
+                           int H, int W, float* dst, hipStream_t stream);
+
+/* timestep_embedding (nn_new.py:103-121): out[n] = [cos(t_n f_i) | sin(t_n f_i)], f32. */
+int flair_timestep_embedding(const float* t, int N, int dim, float max_period, float* out,
+                             hipStream_t stream);
+
+/* y = act_out(act_in(x) @ w^T + bias), f32, M <= 32 rows (one per frame).  Replaces the
+ * time_embed MLP (unet_new.py:980-984,1351) and every emb_layers Linear (:258-264,:399). */
+int flair_linear_f32(const float* x, int M, int K, const float* w, const float* bias, int N,
+                     int act_in, int act_out, float* y, int y_ld, hipStream_t stream);
+
+/* ------------------------------------------------------------------- sampler step
+ * flair_predict_xstart: x0 = clamp(c_recip*x - c_recipm1*eps) with eps = first C of Cm
+ * model channels (gaussian_diffusion.py:278-327).  flair_sampler_update: data
+ * consistency x0 -= gamma*restored (+clamp), aux blend w*x0 + (1-w)*clamp(aux), prev_recon
+ * pinning of the first prev_frames frames, eps' and the generalised DDIM update
+ * (gaussian_diffusion.py:465-515).  All tensors (N,C,H,W) f32, flat length n. */
+typedef struct {
+    float gamma, w_aux;
+    float sqrt_recip_alphas_cumprod, sqrt_recipm1_alphas_cumprod;
+    float sqrt_alphas_cumprod_prev, sqrt_one_minus_alphas_cumprod_prev;
+    float sqrt_one_minus_rho, sqrt_rho;
+    int clip_denoised, nonzero;
+    long frame_elems;
+    int frames, prev_frames;
+} flair_sampler_coefs;
+
+int flair_predict_xstart(const float* x, const float* model_out, int N, int C, int Cm, int H, int W,
+                         float c_recip, float c_recipm1, int clip, float* x0, hipStream_t stream);
+int flair_sampler_update(const flair_sampler_coefs* c, const float* x, float* x0,
+                         const float* restored, const float* aux, const float* z,
+                         const float* prev_recon, long n, float* x_prev, hipStream_t stream);
+int flair_axpby_f32(const float* x, const float* y, float a, float b, long n, float* out,
+                    hipStream_t stream);
+/* x[p][:] *= wmap[p]  (BasicVSR++ per-pixel vsrpp_weights, unet_new.py:739). */
+int flair_scale_pixels(void* x, int dtype, int ld, int C, long P, const float* wmap,
+                       hipStream_t stream);
+
+/* ---------------------------------------------------------------------- attention
+ * Spatial attention over the L tokens of each frame, per head of width 64
+ * (unet_new.py:540-605).  qkv: [frames][L][ld]; q/k/v of head h start at channel
+ * {q,k,v}_off + h*head_stride (legacy order: 0/64/128 + h*192; new order: 0/C/2C + h*64);
+ * out: [frames][L][out_ld], channel h*64 + d.  scale multiplies q.k (1/sqrt(64)). */
+typedef struct {
+    int dtype;
+    int frames, L, heads, head_dim;
+    int ld, out_ld;
+    int q_off, k_off, v_off, head_stride;
+    float scale;
+} flair_attn_params;
+int flair_qkv_attention(const flair_attn_params* p, const void* qkv, void* out, hipStream_t stream);
+
+/* Temporal window attention per pixel (unet_new.py:473-515 + nn.py:370-386): query = own
+ * frame, keys/values = the window-1 neighbouring frames (replicate padded), softmax scale
+ * `scale`.  qkv: [T][H*W][ld] holding q|k|v (C each); kpos: [window-1][C] f32 added to the
+ * keys of each window slot (W_k applied to the positional code of that offset);
+ * round_fp16 reproduces the reference's fp16 cast of q/k/v and of the result. */
+typedef struct {
+    int dtype;
+    int T, H, W, C, window;
+    int ld, out_ld;
+    int round_fp16;
+    float scale;
+} flair_tattn_params;
+int flair_temporal_attention(const flair_tattn_params* p, const void* qkv, const float* kpos,
+                             void* out, hipStream_t stream);
+
+/* ------------------------------------------------------------------ warps / resize
+ * flow_warp (mmedit; unet_new.py:706,718,719): y[p] = bilinear(x, p + flow[p]),
+ * flow [F][H][W][2] f32 = (dx,dy), align_corners=True, zeros (border=0) or border padding. */
+int flair_flow_warp(const void* x, int dtype, int x_ld, const float* flow, int F, int H, int W,
+                    int C, int border, void* y, int y_ld, hipStream_t stream);
+/* out = f1 + warp(f2, f1) on flow fields (unet_new.py:716-718). */
+int flair_flow_compose(const float* f1, const float* f2, int F, int H, int W, float* out,
+                       hipStream_t stream);
+/* mode 0/1: bilinear (align_corners False/True), 2: bicubic (A=-0.75), 3: 2x2 avg-pool;
+ * channel 0 / 1 of the result are multiplied by scale_c0 / scale_c1 (flow rescaling). */
+int flair_resize_nhwc(const void* x, int dtype, int x_ld, int F, int Hi, int Wi, int C, int mode,
+                      int Ho, int Wo, void* y, int y_ld, float scale_c0, float scale_c1,
+                      hipStream_t stream);
+
+/* ------------------------------------------------- deformable alignment (DCNv2)
+ * Fused offset/mask activation + modulated deformable 3x3 conv (unet_new.py:877-898;
+ * same operator as dcn/src/deform_conv_cuda_kernel.cu:571-633 + deform_conv_cuda.cpp:540-560).
+ *   x0|x1 : the two halves of the 2c input channels (feat_prop | feat_n2)
+ *   raw   : conv_offset output, 27*G channels (o1 | o2 | mask), pixel stride raw_ld
+ *   flow1, flow2 : [F][H][W][2] f32 or NULL (zero);  w : [Cout][9][Cin];  bias f32 */
+typedef struct {
+    int dtype;
+    int F, H, W;
+    int Cin, Cout, G;
+    int x_ld[2];
+    int raw_ld, y_ld;
+    float max_residue_magnitude;
+} flair_dcn_params;
+int flair_dcn_align(const flair_dcn_params* p, const void* x0, const void* x1, const void* raw,
+                    const float* flow1, const float* flow2, const void* w, const float* bias,
+                    void* y, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLAIR_HIP_H */
