@@ -143,6 +143,44 @@ __global__ void scale_pixels_kernel(E* x, int ld, int C, long P, const float* wm
     }
 }
 
+
+// out[p][c] = (clamp(x[p][c]*a + b, lo, hi) - sub[c]) * mul[c]   (f32 clip tensors; SPyNet
+// input normalisation, unet_new.py:1300 + mmedit SPyNet mean/std)
+__global__ void affine_channels_kernel(const float* x, int xLd, int C, long P, float a, float b, float lo,
+                                       float hi, const float* sub, const float* mul, float* y, int yLd) {
+    const long total = P * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long p = i / C;
+        const int c = (int)(i % C);
+        float v = fminf(fmaxf(x[p * xLd + c] * a + b, lo), hi);
+        y[p * yLd + c] = (v - (sub ? sub[c] : 0.f)) * (mul ? mul[c] : 1.f);
+    }
+}
+
+// x[f][p][c] += bias[f][c]  (AttentionbottleBlock: h + emb_out, unet_new.py:426-428)
+template <typename E>
+__global__ void add_frame_bias_kernel(E* x, int ld, int C, int F, long HW, const float* bias, int bLd) {
+    const long total = (long)F * HW * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long p = i / C;
+        const long f = p / HW;
+        E* e = x + p * ld + c;
+        ET<E>::st(e, ET<E>::ld(e) + bias[f * bLd + c]);
+    }
+}
+
+// dst[p][coff + c] = (E) src[p][c]  for c < C   (f32 flow fields into a conv input segment)
+template <typename E>
+__global__ void cast_channels_kernel(const float* src, int sLd, int C, long P, E* dst, int dLd, int coff) {
+    const long total = P * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long p = i / C;
+        const int c = (int)(i % C);
+        ET<E>::st(dst + p * dLd + coff + c, src[p * sLd + c]);
+    }
+}
+
 inline int grid_for(long n, int block = 256, int cap = 2048) {
     long g = (n + block - 1) / block;
     if (g > cap) g = cap;
@@ -262,6 +300,47 @@ extern "C" int flair_scale_pixels(void* x, int dtype, int ld, int C, long P, con
         hipLaunchKernelGGL(scale_pixels_kernel<float>, dim3(grid_for(P * (C / 4))), dim3(256), 0, stream, (float*)x,
                            ld, C, P, wmap);
     }
+    FLAIR_LAUNCH_CHECK();
+    return FLAIR_OK;
+}
+
+extern "C" int flair_affine_channels_f32(const float* x, int x_ld, int C, long P, float a, float b, float lo,
+                                         float hi, const float* sub, const float* mul, float* y, int y_ld,
+                                         hipStream_t stream) {
+    FLAIR_CHECK(x && y && C > 0 && P > 0 && x_ld >= C && y_ld >= C, "flair_affine_channels_f32: bad argument");
+    hipLaunchKernelGGL(affine_channels_kernel, dim3(grid_for(P * C)), dim3(256), 0, stream, x, x_ld, C, P, a, b, lo,
+                       hi, sub, mul, y, y_ld);
+    FLAIR_LAUNCH_CHECK();
+    return FLAIR_OK;
+}
+
+extern "C" int flair_add_frame_bias(void* x, int dtype, int ld, int C, int F, long HW, const float* bias,
+                                    int bias_ld, hipStream_t stream) {
+    FLAIR_CHECK(x && bias && C > 0 && F > 0 && HW > 0 && ld >= C && bias_ld >= C, "flair_add_frame_bias: bad argument");
+    if (dtype == FLAIR_BF16)
+        hipLaunchKernelGGL(add_frame_bias_kernel<bf16_t>, dim3(grid_for(F * HW * C)), dim3(256), 0, stream,
+                           (bf16_t*)x, ld, C, F, HW, bias, bias_ld);
+    else if (dtype == FLAIR_F32)
+        hipLaunchKernelGGL(add_frame_bias_kernel<float>, dim3(grid_for(F * HW * C)), dim3(256), 0, stream, (float*)x,
+                           ld, C, F, HW, bias, bias_ld);
+    else
+        FLAIR_CHECK(false, "flair_add_frame_bias: bad dtype");
+    FLAIR_LAUNCH_CHECK();
+    return FLAIR_OK;
+}
+
+extern "C" int flair_cast_channels(const float* src, int src_ld, int C, long P, void* dst, int dtype, int dst_ld,
+                                   int dst_coff, hipStream_t stream) {
+    FLAIR_CHECK(src && dst && C > 0 && P > 0 && src_ld >= C && dst_coff >= 0 && dst_coff + C <= dst_ld,
+                "flair_cast_channels: bad argument");
+    if (dtype == FLAIR_BF16)
+        hipLaunchKernelGGL(cast_channels_kernel<bf16_t>, dim3(grid_for(P * C)), dim3(256), 0, stream, src, src_ld, C,
+                           P, (bf16_t*)dst, dst_ld, dst_coff);
+    else if (dtype == FLAIR_F32)
+        hipLaunchKernelGGL(cast_channels_kernel<float>, dim3(grid_for(P * C)), dim3(256), 0, stream, src, src_ld, C, P,
+                           (float*)dst, dst_ld, dst_coff);
+    else
+        FLAIR_CHECK(false, "flair_cast_channels: bad dtype");
     FLAIR_LAUNCH_CHECK();
     return FLAIR_OK;
 }

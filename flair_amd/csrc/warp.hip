@@ -22,7 +22,7 @@ __device__ __forceinline__ float gs_coord(float pix, int size) {
 }
 
 template <typename E>
-__global__ void flow_warp_kernel(const E* x, int xLd, const float* flow, int F, int H, int W, int C, int border,
+__global__ void flow_warp_kernel(const E* x, int xLd, const float* flow, int fLd, int F, int H, int W, int C, int border,
                                  E* y, int yLd) {
     constexpr int VEC = ET<E>::VEC;
     const int cv = C / VEC;
@@ -33,7 +33,7 @@ __global__ void flow_warp_kernel(const E* x, int xLd, const float* flow, int F, 
         const int w = (int)(p % W);
         const int h = (int)((p / W) % H);
         const long f = p / ((long)W * H);
-        const float2 fl = *reinterpret_cast<const float2*>(flow + p * 2);
+        const float2 fl = *reinterpret_cast<const float2*>(flow + p * fLd);
         float ix = gs_coord((float)w + fl.x, W);
         float iy = gs_coord((float)h + fl.y, H);
         if (border) {
@@ -163,17 +163,18 @@ inline int grid_for(long n) {
 
 }  // namespace
 
-extern "C" int flair_flow_warp(const void* x, int dtype, int x_ld, const float* flow, int F, int H, int W, int C,
-                               int border, void* y, int y_ld, hipStream_t stream) {
-    FLAIR_CHECK(x && flow && y && F > 0 && H > 0 && W > 0 && C > 0, "flair_flow_warp: bad argument");
+extern "C" int flair_flow_warp(const void* x, int dtype, int x_ld, const float* flow, int flow_ld, int F, int H,
+                               int W, int C, int border, void* y, int y_ld, hipStream_t stream) {
+    FLAIR_CHECK(x && flow && y && F > 0 && H > 0 && W > 0 && C > 0 && flow_ld >= 2 && flow_ld % 2 == 0,
+                "flair_flow_warp: bad argument");
     if (dtype == FLAIR_BF16) {
         FLAIR_CHECK(C % 8 == 0 && x_ld % 8 == 0 && y_ld % 8 == 0, "flair_flow_warp: bf16 needs C %% 8 == 0");
         hipLaunchKernelGGL(flow_warp_kernel<bf16_t>, dim3(grid_for((long)F * H * W * (C / 8))), dim3(256), 0, stream,
-                           (const bf16_t*)x, x_ld, flow, F, H, W, C, border, (bf16_t*)y, y_ld);
+                           (const bf16_t*)x, x_ld, flow, flow_ld, F, H, W, C, border, (bf16_t*)y, y_ld);
     } else if (dtype == FLAIR_F32) {
         FLAIR_CHECK(C % 4 == 0 && x_ld % 4 == 0 && y_ld % 4 == 0, "flair_flow_warp: f32 needs C %% 4 == 0");
         hipLaunchKernelGGL(flow_warp_kernel<float>, dim3(grid_for((long)F * H * W * (C / 4))), dim3(256), 0, stream,
-                           (const float*)x, x_ld, flow, F, H, W, C, border, (float*)y, y_ld);
+                           (const float*)x, x_ld, flow, flow_ld, F, H, W, C, border, (float*)y, y_ld);
     } else {
         FLAIR_CHECK(false, "flair_flow_warp: bad dtype");
     }

@@ -1,0 +1,395 @@
+"""Tensor-level wrappers over the C ABI (include/flair_hip.h).
+
+Every function takes torch tensors that live in HBM, passes raw pointers / sizes to
+libflair_hip.so on torch's current HIP stream and returns torch tensors.  Activations
+are *clip tensors*: shape (T, H, W, C), C innermost, dtype float32 or bfloat16.
+PyTorch only provides memory and streams here; no torch operator computes anything.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_LRELU01, ACT_NONE, ACT_RELU, ACT_SILU, ConvParams, check, dtype_code, lib,
+                   ptr, stream)
+
+__all__ = ["conv", "group_norm", "nchw_to_clip", "clip_to_nchw", "timestep_embedding", "linear",
+           "qkv_attention", "temporal_attention", "flow_warp", "flow_compose", "resize",
+           "dcn_align", "scale_pixels", "predict_xstart", "sampler_update",
+           "ACT_NONE", "ACT_RELU", "ACT_LRELU01", "ACT_SILU"]
+
+
+class GnParams(ctypes.Structure):
+    _fields_ = [("dtype", ctypes.c_int), ("C", ctypes.c_int), ("c0", ctypes.c_int),
+                ("ld0", ctypes.c_int), ("ld1", ctypes.c_int), ("groups", ctypes.c_int),
+                ("F", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int),
+                ("frames_per_stat", ctypes.c_int), ("eps", ctypes.c_float), ("act", ctypes.c_int),
+                ("resample", ctypes.c_int), ("y_ld", ctypes.c_int), ("raw_ld", ctypes.c_int),
+                ("film_ld", ctypes.c_int)]
+
+
+class SamplerCoefs(ctypes.Structure):
+    _fields_ = [("gamma", ctypes.c_float), ("w_aux", ctypes.c_float),
+                ("sqrt_recip_alphas_cumprod", ctypes.c_float),
+                ("sqrt_recipm1_alphas_cumprod", ctypes.c_float),
+                ("sqrt_alphas_cumprod_prev", ctypes.c_float),
+                ("sqrt_one_minus_alphas_cumprod_prev", ctypes.c_float),
+                ("sqrt_one_minus_rho", ctypes.c_float), ("sqrt_rho", ctypes.c_float),
+                ("clip_denoised", ctypes.c_int), ("nonzero", ctypes.c_int),
+                ("frame_elems", ctypes.c_long), ("frames", ctypes.c_int),
+                ("prev_frames", ctypes.c_int)]
+
+
+class AttnParams(ctypes.Structure):
+    _fields_ = [("dtype", ctypes.c_int), ("frames", ctypes.c_int), ("L", ctypes.c_int),
+                ("heads", ctypes.c_int), ("head_dim", ctypes.c_int), ("ld", ctypes.c_int),
+                ("out_ld", ctypes.c_int), ("q_off", ctypes.c_int), ("k_off", ctypes.c_int),
+                ("v_off", ctypes.c_int), ("head_stride", ctypes.c_int), ("scale", ctypes.c_float)]
+
+
+class TAttnParams(ctypes.Structure):
+    _fields_ = [("dtype", ctypes.c_int), ("T", ctypes.c_int), ("H", ctypes.c_int),
+                ("W", ctypes.c_int), ("C", ctypes.c_int), ("window", ctypes.c_int),
+                ("ld", ctypes.c_int), ("out_ld", ctypes.c_int), ("round_fp16", ctypes.c_int),
+                ("scale", ctypes.c_float)]
+
+
+class DcnParams(ctypes.Structure):
+    _fields_ = [("dtype", ctypes.c_int), ("F", ctypes.c_int), ("H", ctypes.c_int),
+                ("W", ctypes.c_int), ("Cin", ctypes.c_int), ("Cout", ctypes.c_int),
+                ("G", ctypes.c_int), ("x_ld", ctypes.c_int * 2), ("raw_ld", ctypes.c_int),
+                ("y_ld", ctypes.c_int), ("max_residue_magnitude", ctypes.c_float)]
+
+
+def _ld(t):
+    """Pixel stride (elements) of a clip tensor or channel-slice view of one."""
+    assert t.dim() == 4 and t.stride(3) == 1, "clip tensors are (T,H,W,C) with C innermost"
+    ld = t.stride(2)
+    assert t.stride(1) == ld * t.shape[2] and (t.shape[0] == 1 or t.stride(0) == ld * t.shape[1] * t.shape[2]), \
+        "clip tensor must be dense over (T,H,W)"
+    return ld
+
+
+def _f32(t):
+    assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
+    return t
+
+
+def k_align(dtype):
+    """Channel granularity of a conv input segment (one 64-byte K step)."""
+    return 32 if dtype == torch.bfloat16 else 16
+
+
+def pad_channels(c, dtype):
+    g = k_align(dtype)
+    return (c + g - 1) // g * g
+
+
+# --------------------------------------------------------------------------- conv
+def conv(xs, weight, bias, cout, kernel, *, out=None, act=ACT_NONE, res0=None, res1=None,
+         out_scale=1.0):
+    """Y = act(conv(cat(xs), W) + bias) + res0 + res1, times out_scale.
+
+    xs: one clip tensor or a list of up to 4 (channel-concatenated implicitly; each
+    width a multiple of ``k_align``); weight: packed [cout][taps][sum C] in the
+    activation dtype; kernel: (KT, KH, KW); out: optional (T,H,W,>=cout) view.
+    """
+    if isinstance(xs, torch.Tensor):
+        xs = [xs]
+    x0 = xs[0]
+    T, H, W, _ = x0.shape
+    p = ConvParams()
+    p.dtype = dtype_code(x0)
+    p.T, p.H, p.W = T, H, W
+    p.KT, p.KH, p.KW = kernel
+    p.Cout = cout
+    p.nseg = len(xs)
+    arr = (ctypes.c_void_p * 4)()
+    for i, x in enumerate(xs):
+        assert x.dtype == x0.dtype and x.shape[:3] == x0.shape[:3]
+        p.seg_c[i] = x.shape[3]
+        p.seg_ld[i] = _ld(x)
+        arr[i] = x.data_ptr()
+    if out is None:
+        out = torch.empty((T, H, W, cout), dtype=x0.dtype, device=x0.device)
+    assert out.shape[:3] == x0.shape[:3] and out.shape[3] >= cout and out.dtype == x0.dtype
+    p.y_ld = _ld(out)
+    p.res_ld[0] = _ld(res0) if res0 is not None else 0
+    p.res_ld[1] = _ld(res1) if res1 is not None else 0
+    p.act = act
+    p.out_scale = out_scale
+    assert weight.dtype == x0.dtype and weight.is_contiguous()
+    check(lib().flair_conv_nhwc(ctypes.byref(p), arr, ptr(weight), ptr(_f32(bias)), ptr(res0),
+                                ptr(res1), ptr(out), stream()), "flair_conv_nhwc")
+    return out
+
+
+def pack_conv_weight(w, seg_channels, dtype, cout_pad=None):
+    """Reference layout (Cout, Cin, *k) f32 -> [Cout_pad][taps][sum padded seg] in `dtype`.
+
+    ``seg_channels``: list of (real, padded) channel counts of the input segments, in
+    concatenation order.  One-time repack at load (plain tensor plumbing).
+    """
+    cout, cin = w.shape[:2]
+    taps = 1
+    for k in w.shape[2:]:
+        taps *= k
+    w = w.reshape(cout, cin, taps).permute(0, 2, 1).float()  # cout, taps, cin
+    parts, o = [], 0
+    for real, padded in seg_channels:
+        seg = w[:, :, o:o + real]
+        if padded > real:
+            seg = torch.cat([seg, seg.new_zeros(cout, taps, padded - real)], dim=2)
+        parts.append(seg)
+        o += real
+    assert o == cin, (o, cin)
+    w = torch.cat(parts, dim=2)
+    if cout_pad is not None and cout_pad > cout:
+        w = torch.cat([w, w.new_zeros(cout_pad - cout, taps, w.shape[2])], dim=0)
+    return w.to(dtype).contiguous()
+
+
+# --------------------------------------------------------------------- group norm
+_gn_ws = {}
+
+
+def _workspace(nbytes, device):
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    buf = _gn_ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _gn_ws[key] = buf
+    return buf
+
+
+def group_norm(x, gamma, beta, *, x1=None, groups=32, eps=1e-5, act=ACT_NONE, film=None,
+               frames_per_stat=None, resample=0, out=None, want_raw=False):
+    """act(GN(cat(x, x1)) * (1+scale) + shift) with optional 2x resampling.
+
+    film: (F, >=2C) f32 rows (scale | shift) or None.  resample: 0 / 1 (avg-pool 2) /
+    2 (nearest x2).  Returns y, or (y, raw) when ``want_raw``.
+    """
+    T, H, W, c0 = x.shape
+    C = c0 + (x1.shape[3] if x1 is not None else 0)
+    p = GnParams()
+    p.dtype = dtype_code(x)
+    p.C, p.c0 = C, c0
+    p.ld0 = _ld(x)
+    p.ld1 = _ld(x1) if x1 is not None else 0
+    p.groups = groups
+    p.F, p.H, p.W = T, H, W
+    p.frames_per_stat = frames_per_stat or T
+    p.eps = eps
+    p.act = act
+    p.resample = resample
+    Ho, Wo = (H // 2, W // 2) if resample == 1 else ((H * 2, W * 2) if resample == 2 else (H, W))
+    if out is None:
+        out = torch.empty((T, Ho, Wo, C), dtype=x.dtype, device=x.device)
+    raw = torch.empty((T, Ho, Wo, C), dtype=x.dtype, device=x.device) if want_raw else None
+    p.y_ld = _ld(out)
+    p.raw_ld = _ld(raw) if raw is not None else 0
+    p.film_ld = film.stride(0) if film is not None else 0
+    if film is not None:
+        assert film.dtype == torch.float32 and film.stride(1) == 1 and film.shape[0] == T
+    ws = _workspace(lib_ws_bytes(p), x.device)
+    check(lib().flair_groupnorm_nhwc(ctypes.byref(p), ptr(x), ptr(x1), ptr(_f32(gamma)), ptr(_f32(beta)),
+                                     ptr(film), ptr(out), ptr(raw), ptr(ws), stream()),
+          "flair_groupnorm_nhwc")
+    return (out, raw) if want_raw else out
+
+
+def lib_ws_bytes(p):
+    f = lib().flair_groupnorm_workspace_bytes
+    f.restype = ctypes.c_size_t
+    return f(ctypes.byref(p))
+
+
+# ------------------------------------------------------------------ edge / small ops
+def nchw_to_clip(src, dst, coff=0):
+    """(N,C,H,W) f32 -> channels [coff, coff+C) of clip tensor dst (N,H,W,Cd)."""
+    N, C, H, W = src.shape
+    assert src.dtype == torch.float32 and src.is_contiguous()
+    check(lib().flair_nchw_f32_to_nhwc(ptr(src), N, C, H, W, ptr(dst), dtype_code(dst), _ld(dst), coff,
+                                       stream()), "flair_nchw_f32_to_nhwc")
+    return dst
+
+
+def clip_to_nchw(src, C, coff=0, out=None):
+    N, H, W, _ = src.shape
+    if out is None:
+        out = torch.empty((N, C, H, W), dtype=torch.float32, device=src.device)
+    check(lib().flair_nhwc_to_nchw_f32(ptr(src), dtype_code(src), _ld(src), coff, N, C, H, W, ptr(out),
+                                       stream()), "flair_nhwc_to_nchw_f32")
+    return out
+
+
+def timestep_embedding(t, dim, max_period=10000.0, out=None):
+    """t: (N,) f32 device tensor -> (N, dim) f32."""
+    assert t.dtype == torch.float32 and t.is_contiguous()
+    N = t.shape[0]
+    if out is None:
+        out = torch.empty((N, dim), dtype=torch.float32, device=t.device)
+    check(lib().flair_timestep_embedding(ptr(t), N, dim, ctypes.c_float(max_period), ptr(out), stream()),
+          "flair_timestep_embedding")
+    return out
+
+
+def linear(x, w, b, *, act_in=ACT_NONE, act_out=ACT_NONE, out=None):
+    """f32 (M<=32, K) @ (N, K)^T + b."""
+    M, K = x.shape
+    N = w.shape[0]
+    assert x.dtype == torch.float32 and w.dtype == torch.float32 and x.is_contiguous() and w.is_contiguous()
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    check(lib().flair_linear_f32(ptr(x), M, K, ptr(w), ptr(b), N, act_in, act_out, ptr(out), out.stride(0),
+                                 stream()), "flair_linear_f32")
+    return out
+
+
+def qkv_attention(qkv, heads, *, new_order=False, out=None):
+    """qkv: (F, H, W, 3C) clip tensor -> (F, H, W, C)."""
+    F_, H, W, C3 = qkv.shape
+    C = C3 // 3
+    p = AttnParams()
+    p.dtype = dtype_code(qkv)
+    p.frames, p.L, p.heads, p.head_dim = F_, H * W, heads, C // heads
+    p.ld = _ld(qkv)
+    if out is None:
+        out = torch.empty((F_, H, W, C), dtype=qkv.dtype, device=qkv.device)
+    p.out_ld = _ld(out)
+    d = C // heads
+    if new_order:
+        p.q_off, p.k_off, p.v_off, p.head_stride = 0, C, 2 * C, d
+    else:
+        p.q_off, p.k_off, p.v_off, p.head_stride = 0, d, 2 * d, 3 * d
+    p.scale = 1.0 / (d ** 0.5)
+    check(lib().flair_qkv_attention(ctypes.byref(p), ptr(qkv), ptr(out), stream()), "flair_qkv_attention")
+    return out
+
+
+def temporal_attention(qkv, kpos, window, *, round_fp16, out=None):
+    T, H, W, C3 = qkv.shape
+    C = C3 // 3
+    p = TAttnParams()
+    p.dtype = dtype_code(qkv)
+    p.T, p.H, p.W, p.C, p.window = T, H, W, C, window
+    p.ld = _ld(qkv)
+    if out is None:
+        out = torch.empty((T, H, W, C), dtype=qkv.dtype, device=qkv.device)
+    p.out_ld = _ld(out)
+    p.round_fp16 = int(round_fp16)
+    p.scale = 1.0 / (64 ** 0.5)
+    assert kpos.shape == (window - 1, C)
+    check(lib().flair_temporal_attention(ctypes.byref(p), ptr(qkv), ptr(_f32(kpos)), ptr(out), stream()),
+          "flair_temporal_attention")
+    return out
+
+
+def flow_warp(x, flow, *, border=False, out=None):
+    """x: (F,H,W,C) clip tensor; flow: (F,H,W,2) f32 (dx,dy)."""
+    F_, H, W, C = x.shape
+    assert flow.dtype == torch.float32 and flow.shape == (F_, H, W, 2)
+    if out is None:
+        out = torch.empty((F_, H, W, C), dtype=x.dtype, device=x.device)
+    check(lib().flair_flow_warp(ptr(x), dtype_code(x), _ld(x), ptr(flow), _ld(flow), F_, H, W, C, int(border),
+                                ptr(out), _ld(out), stream()), "flair_flow_warp")
+    return out
+
+
+def flow_compose(f1, f2, out=None):
+    F_, H, W, _ = f1.shape
+    assert f1.dtype == torch.float32 and f1.is_contiguous() and f2.is_contiguous()
+    if out is None:
+        out = torch.empty_like(f1)
+    check(lib().flair_flow_compose(ptr(f1), ptr(f2), F_, H, W, ptr(out), stream()), "flair_flow_compose")
+    return out
+
+
+RESIZE_BILINEAR, RESIZE_BILINEAR_AC, RESIZE_BICUBIC, RESIZE_AVGPOOL2 = 0, 1, 2, 3
+
+
+def resize(x, size, mode, *, channels=None, out=None, scale_c0=1.0, scale_c1=1.0):
+    F_, Hi, Wi, Cx = x.shape
+    C = channels or Cx
+    Ho, Wo = size
+    if out is None:
+        out = torch.zeros((F_, Ho, Wo, Cx), dtype=x.dtype, device=x.device)
+    check(lib().flair_resize_nhwc(ptr(x), dtype_code(x), _ld(x), F_, Hi, Wi, C, mode, Ho, Wo, ptr(out), _ld(out),
+                                  ctypes.c_float(scale_c0), ctypes.c_float(scale_c1), stream()),
+          "flair_resize_nhwc")
+    return out
+
+
+def dcn_align(x0, x1, raw, flow1, flow2, weight, bias, cout, *, groups=16, max_mag=10.0, out=None):
+    F_, H, W, ch = x0.shape
+    p = DcnParams()
+    p.dtype = dtype_code(x0)
+    p.F, p.H, p.W = F_, H, W
+    p.Cin, p.Cout, p.G = 2 * ch, cout, groups
+    p.x_ld[0], p.x_ld[1] = _ld(x0), _ld(x1)
+    p.raw_ld = _ld(raw)
+    if out is None:
+        out = torch.empty((F_, H, W, cout), dtype=x0.dtype, device=x0.device)
+    p.y_ld = _ld(out)
+    p.max_residue_magnitude = max_mag
+    check(lib().flair_dcn_align(ctypes.byref(p), ptr(x0), ptr(x1), ptr(raw), ptr(flow1), ptr(flow2), ptr(weight),
+                                ptr(_f32(bias)), ptr(out), stream()), "flair_dcn_align")
+    return out
+
+
+def scale_pixels(x, wmap):
+    T, H, W, C = x.shape
+    check(lib().flair_scale_pixels(ptr(x), dtype_code(x), _ld(x), C, ctypes.c_long(T * H * W), ptr(_f32(wmap)),
+                                   stream()), "flair_scale_pixels")
+    return x
+
+
+# ------------------------------------------------------------------------ sampler
+def predict_xstart(x, model_out, c_recip, c_recipm1, clip, out=None):
+    N, C, H, W = x.shape
+    Cm = model_out.shape[1]
+    assert x.dtype == torch.float32 and x.is_contiguous() and model_out.is_contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib().flair_predict_xstart(ptr(x), ptr(model_out), N, C, Cm, H, W, ctypes.c_float(c_recip),
+                                     ctypes.c_float(c_recipm1), int(clip), ptr(out), stream()),
+          "flair_predict_xstart")
+    return out
+
+
+def sampler_update(coefs, x, x0, restored, aux, z, prev_recon, out=None):
+    if out is None:
+        out = torch.empty_like(x)
+    for t in (x, x0, restored, aux, z, prev_recon):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
+    check(lib().flair_sampler_update(ctypes.byref(coefs), ptr(x), ptr(x0), ptr(restored), ptr(aux), ptr(z),
+                                     ptr(prev_recon), ctypes.c_long(x.numel()), ptr(out), stream()),
+          "flair_sampler_update")
+    return out
+
+
+def affine_channels(x, C, a, b, lo, hi, sub, mul, out):
+    """f32 clip tensors: out = (clamp(x*a+b, lo, hi) - sub[c]) * mul[c] on the first C channels."""
+    T, H, W, _ = x.shape
+    assert x.dtype == torch.float32 and out.dtype == torch.float32
+    check(lib().flair_affine_channels_f32(ptr(x), _ld(x), C, ctypes.c_long(T * H * W), ctypes.c_float(a),
+                                          ctypes.c_float(b), ctypes.c_float(lo), ctypes.c_float(hi), ptr(sub),
+                                          ptr(mul), ptr(out), _ld(out), stream()), "flair_affine_channels_f32")
+    return out
+
+
+def add_frame_bias(x, bias):
+    T, H, W, C = x.shape
+    assert bias.dtype == torch.float32 and bias.stride(1) == 1
+    check(lib().flair_add_frame_bias(ptr(x), dtype_code(x), _ld(x), C, T, ctypes.c_long(H * W), ptr(bias),
+                                     bias.stride(0), stream()), "flair_add_frame_bias")
+    return x
+
+
+def cast_channels(src, dst, coff=0):
+    """src: (T,H,W,C) f32 -> channels [coff, coff+C) of clip tensor dst."""
+    T, H, W, C = src.shape
+    assert src.dtype == torch.float32
+    check(lib().flair_cast_channels(ptr(src), _ld(src), C, ctypes.c_long(T * H * W), ptr(dst), dtype_code(dst),
+                                    _ld(dst), coff, stream()), "flair_cast_channels")
+    return dst

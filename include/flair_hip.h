@@ -157,6 +157,18 @@ int flair_sampler_update(const flair_sampler_coefs* c, const float* x, float* x0
                          const float* prev_recon, long n, float* x_prev, hipStream_t stream);
 int flair_axpby_f32(const float* x, const float* y, float a, float b, long n, float* out,
                     hipStream_t stream);
+/* y[p][c] = (clamp(x[p][c]*a + b, lo, hi) - sub[c]) * mul[c] on f32 pixels (SPyNet input
+ * normalisation: unet_new.py:1300 and mmedit SPyNet's mean/std). */
+int flair_affine_channels_f32(const float* x, int x_ld, int C, long P, float a, float b, float lo,
+                              float hi, const float* sub, const float* mul, float* y, int y_ld,
+                              hipStream_t stream);
+/* x[f][p][c] += bias[f][c]  (AttentionbottleBlock h + emb_out, unet_new.py:426-428). */
+int flair_add_frame_bias(void* x, int dtype, int ld, int C, int F, long HW, const float* bias,
+                         int bias_ld, hipStream_t stream);
+/* dst[p][coff+c] = cast(src[p][c]): f32 flow fields into a conv input segment (th.cat at
+ * unet_new.py:875). */
+int flair_cast_channels(const float* src, int src_ld, int C, long P, void* dst, int dtype,
+                        int dst_ld, int dst_coff, hipStream_t stream);
 /* x[p][:] *= wmap[p]  (BasicVSR++ per-pixel vsrpp_weights, unet_new.py:739). */
 int flair_scale_pixels(void* x, int dtype, int ld, int C, long P, const float* wmap,
                        hipStream_t stream);
@@ -192,9 +204,10 @@ int flair_temporal_attention(const flair_tattn_params* p, const void* qkv, const
 
 /* ------------------------------------------------------------------ warps / resize
  * flow_warp (mmedit; unet_new.py:706,718,719): y[p] = bilinear(x, p + flow[p]),
- * flow [F][H][W][2] f32 = (dx,dy), align_corners=True, zeros (border=0) or border padding. */
-int flair_flow_warp(const void* x, int dtype, int x_ld, const float* flow, int F, int H, int W,
-                    int C, int border, void* y, int y_ld, hipStream_t stream);
+ * flow [F][H][W] pixels of (dx,dy) f32, flow_ld floats apart; align_corners=True, zeros
+ * (border=0) or border padding. */
+int flair_flow_warp(const void* x, int dtype, int x_ld, const float* flow, int flow_ld, int F,
+                    int H, int W, int C, int border, void* y, int y_ld, hipStream_t stream);
 /* out = f1 + warp(f2, f1) on flow fields (unet_new.py:716-718). */
 int flair_flow_compose(const float* f1, const float* f2, int F, int H, int W, float* out,
                        hipStream_t stream);

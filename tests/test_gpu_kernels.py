@@ -1,0 +1,255 @@
+"""Per-kernel parity: HIP path (through the C ABI) vs the CPU oracle / plain torch fp32.
+
+Run on the GPU box with ``pytest -m gpu``.  Integer-free floating point work: the
+tolerance per dtype is stated in tests/util.py.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import assert_close, from_clip, rb, to_clip
+
+pytestmark = pytest.mark.gpu
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _ops():
+    from flair_amd import ops
+    return ops
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [
+    # T, H, W, segs, cout, kernel, act, nres
+    (2, 16, 16, [64], 64, (1, 3, 3), 0, 0),
+    (3, 20, 12, [64, 32], 128, (1, 3, 3), 2, 1),
+    (4, 8, 8, [32], 96, (3, 3, 3), 0, 2),
+    (1, 9, 7, [32], 16, (1, 7, 7), 1, 0),
+    (2, 16, 16, [128], 432, (1, 3, 3), 0, 0),
+    (5, 6, 6, [64], 8, (1, 1, 1), 3, 0),
+    (1, 64, 64, [64, 64, 64, 32], 64, (1, 3, 3), 2, 0),
+    (16, 4, 4, [512], 512, (3, 3, 3), 0, 1),
+])
+def test_conv(dev, dtype, case):
+    ops = _ops()
+    T, H, W, segs, cout, k, act, nres = case
+    g = torch.Generator().manual_seed(T * 1000 + H * 10 + cout)
+    cin = sum(segs)
+    x = rb(torch.randn(T, cin, H, W, generator=g), dtype)
+    fan = cin * k[0] * k[1] * k[2]
+    w = rb(torch.randn(cout, cin, *k, generator=g) / math.sqrt(fan), dtype)
+    b = torch.randn(cout, generator=g) * 0.1
+    res = [rb(torch.randn(T, cout, H, W, generator=g), dtype) for _ in range(nres)]
+    # reference (fp32, cpu)
+    if k[0] == 1:
+        ref = F.conv2d(x, w[:, :, 0], b, padding=(k[1] // 2, k[2] // 2))
+    else:
+        ref = F.conv3d(x.permute(1, 0, 2, 3)[None], w, b, padding=tuple(v // 2 for v in k))[0].permute(1, 0, 2, 3)
+    ref = {0: lambda v: v, 1: F.relu, 2: lambda v: F.leaky_relu(v, 0.1), 3: F.silu}[act](ref)
+    for r in res:
+        ref = ref + r
+    ref = ref * 0.5
+    xs, o = [], 0
+    for c in segs:
+        xs.append(to_clip(x[:, o:o + c], dtype, dev))
+        o += c
+    wp = ops.pack_conv_weight(w, [(c, c) for c in segs], dtype).to(dev)
+    rs = [to_clip(r, dtype, dev) for r in res] + [None, None]
+    y = ops.conv(xs, wp, b.to(dev), cout, k, act=act, res0=rs[0], res1=rs[1], out_scale=0.5)
+    torch.cuda.synchronize()
+    assert_close(from_clip(y), ref, dtype, f"conv {case}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [
+    # T, H, W, c0, c1, film, resample, fps
+    (4, 16, 16, 64, 0, False, 0, None),
+    (3, 12, 20, 128, 64, True, 0, None),
+    (2, 16, 16, 64, 0, True, 1, None),
+    (2, 8, 8, 256, 0, False, 2, None),
+    (4, 8, 8, 96, 0, True, 0, 1),
+    (16, 4, 4, 1024, 0, True, 0, None),
+])
+def test_group_norm(dev, dtype, case):
+    ops = _ops()
+    T, H, W, c0, c1, film, resample, fps = case
+    C = c0 + c1
+    g = torch.Generator().manual_seed(7 + C)
+    x = rb(torch.randn(T, C, H, W, generator=g) * 1.7 + 0.3, dtype)
+    gamma = torch.randn(C, generator=g)
+    beta = torch.randn(C, generator=g)
+    emb = torch.randn(T, 2 * C + 5, generator=g) * 0.5 if film else None
+    if fps == 1:
+        n = F.group_norm(x, 32, gamma, beta, 1e-5)
+    else:
+        n = F.group_norm(x.permute(1, 0, 2, 3)[None], 32, gamma, beta, 1e-5)[0].permute(1, 0, 2, 3)
+    if film:
+        n = n * (1 + emb[:, :C, None, None]) + emb[:, C:2 * C, None, None]
+    ref = F.silu(n)
+    raw_ref = x
+    if resample == 1:
+        ref, raw_ref = F.avg_pool2d(ref, 2), F.avg_pool2d(x, 2)
+    elif resample == 2:
+        ref, raw_ref = F.interpolate(ref, scale_factor=2, mode="nearest"), F.interpolate(x, scale_factor=2, mode="nearest")
+    xa = to_clip(x[:, :c0], dtype, dev)
+    xb = to_clip(x[:, c0:], dtype, dev) if c1 else None
+    res = ops.group_norm(xa, gamma.to(dev), beta.to(dev), x1=xb, act=ops.ACT_SILU,
+                         film=emb.to(dev) if film else None, frames_per_stat=fps,
+                         resample=resample, want_raw=bool(resample))
+    y, raw = res if resample else (res, None)
+    torch.cuda.synchronize()
+    assert_close(from_clip(y), ref, dtype, f"gn {case}", scale=4.0)
+    if resample:
+        assert_close(from_clip(raw), raw_ref, dtype, f"gn raw {case}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("new_order", [False, True])
+@pytest.mark.parametrize("case", [(2, 4, 4, 2), (3, 8, 8, 4), (2, 16, 16, 4), (1, 32, 32, 1), (1, 12, 12, 2)])
+def test_qkv_attention(dev, dtype, new_order, case):
+    from oracle.unet import qkv_attention_legacy, qkv_attention_new
+    ops = _ops()
+    Fr, H, W, heads = case
+    C = heads * 64
+    g = torch.Generator().manual_seed(11)
+    qkv = rb(torch.randn(Fr, 3 * C, H * W, generator=g) * 1.5, dtype)
+    ref = (qkv_attention_new if new_order else qkv_attention_legacy)(qkv, heads).reshape(Fr, C, H, W)
+    y = ops.qkv_attention(to_clip(qkv.reshape(Fr, 3 * C, H, W), dtype, dev), heads, new_order=new_order)
+    torch.cuda.synchronize()
+    assert_close(from_clip(y), ref, dtype, f"attn {case}", scale=2.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(4, 4, 4, 128), (7, 8, 8, 64), (2, 2, 2, 256)])
+def test_temporal_attention(dev, dtype, case):
+    from oracle.thirdparty import flash_attn_func
+    ops = _ops()
+    T, H, W, C = case
+    heads = C // 64
+    g = torch.Generator().manual_seed(5)
+    qkv = rb(torch.randn(T, 3 * C, H, W, generator=g), dtype)
+    kpos = torch.randn(4, C, generator=g) * 0.3
+    q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    idx = (torch.arange(T).view(T, 1) + torch.tensor([-2, -1, 1, 2]).view(1, 4)).clamp(0, T - 1)
+    kw = k[idx] + kpos.view(1, 4, C, 1, 1)             # T,4,C,H,W
+    vw = v[idx]
+    def tok(z):  # -> (T*H*W, n, heads, 64)
+        n = z.shape[1]
+        return z.permute(0, 3, 4, 1, 2).reshape(T * H * W, n, heads, 64)
+    qq = tok(q[:, None])
+    if dtype == torch.float32:   # reference rounds through fp16 (nn.py:370-386)
+        o = flash_attn_func(qq.half(), tok(kw).half(), tok(vw).half()).float()
+    else:
+        o = flash_attn_func(qq, tok(kw), tok(vw))
+    ref = o.reshape(T, H, W, C).permute(0, 3, 1, 2)
+    y = ops.temporal_attention(to_clip(qkv, dtype, dev), kpos.to(dev), 5, round_fp16=(dtype == torch.float32))
+    torch.cuda.synchronize()
+    # f32 path reproduces the fp16 rounding of the reference: 1 fp16 ulp (2^-10) slack
+    err = (from_clip(y) - ref).abs().max().item()
+    bound = (2e-3 if dtype == torch.float32 else 1.6e-2) * ref.abs().max().item() + 1e-3
+    assert err <= bound, (err, bound)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("border", [False, True])
+def test_flow_warp(dev, dtype, border):
+    from oracle.thirdparty import flow_warp
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    x = rb(torch.randn(3, 64, 12, 10, generator=g), dtype)
+    flow = torch.randn(3, 12, 10, 2, generator=g) * 3.0
+    ref = flow_warp(x, flow, padding_mode="border" if border else "zeros")
+    y = ops.flow_warp(to_clip(x, dtype, dev), flow.to(dev), border=border)
+    torch.cuda.synchronize()
+    assert_close(from_clip(y), ref, dtype, "flow_warp", scale=4.0)
+
+
+def test_flow_compose(dev):
+    from oracle.thirdparty import flow_warp
+    ops = _ops()
+    g = torch.Generator().manual_seed(4)
+    f1 = torch.randn(2, 9, 11, 2, generator=g) * 2
+    f2 = torch.randn(2, 9, 11, 2, generator=g) * 2
+    ref = f1 + flow_warp(f2.permute(0, 3, 1, 2), f1).permute(0, 2, 3, 1)
+    y = ops.flow_compose(f1.to(dev), f2.to(dev))
+    torch.cuda.synchronize()
+    assert_close(y.cpu(), ref, torch.float32, "flow_compose", scale=8.0)
+
+
+@pytest.mark.parametrize("mode,size", [(0, (24, 40)), (0, (10, 7)), (1, (32, 24)), (2, (8, 6)), (2, (40, 30)), (3, (8, 6))])
+def test_resize(dev, mode, size):
+    ops = _ops()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 3, 16, 12, generator=g)
+    if mode == 0:
+        ref = F.interpolate(x, size=size, mode="bilinear", align_corners=False)
+    elif mode == 1:
+        ref = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+    elif mode == 2:
+        ref = F.interpolate(x, size=size, mode="bicubic")
+    else:
+        ref = F.avg_pool2d(x, 2, 2)
+    y = ops.resize(to_clip(x, torch.float32, dev, pad_to=4), size, mode, channels=3)
+    torch.cuda.synchronize()
+    assert_close(from_clip(y, 3), ref, torch.float32, f"resize {mode}", scale=8.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("c", [64, 128])
+def test_dcn(dev, dtype, c):
+    from oracle.thirdparty import deform_conv2d
+    ops = _ops()
+    g = torch.Generator().manual_seed(21 + c)
+    H, W, G = 12, 10, 16
+    x = rb(torch.randn(1, 2 * c, H, W, generator=g), dtype)
+    raw = rb(torch.randn(1, 27 * G, H, W, generator=g), dtype)
+    f1 = torch.randn(1, H, W, 2, generator=g) * 2
+    f2 = torch.randn(1, H, W, 2, generator=g) * 2
+    w = rb(torch.randn(c, 2 * c, 3, 3, generator=g) / math.sqrt(18 * c), dtype)
+    b = torch.randn(c, generator=g) * 0.1
+    o1, o2, mask = raw.chunk(3, dim=1)
+    offset = 10 * torch.tanh(torch.cat((o1, o2), dim=1))
+    off1, off2 = offset.chunk(2, dim=1)
+    off1 = off1 + f1.permute(0, 3, 1, 2).flip(1).repeat(1, off1.shape[1] // 2, 1, 1)
+    off2 = off2 + f2.permute(0, 3, 1, 2).flip(1).repeat(1, off2.shape[1] // 2, 1, 1)
+    ref = deform_conv2d(x, torch.cat([off1, off2], 1), w, b, (1, 1), (1, 1), (1, 1), torch.sigmoid(mask))
+    wp = ops.pack_conv_weight(w, [(2 * c, 2 * c)], dtype).to(dev)
+    y = ops.dcn_align(to_clip(x[:, :c], dtype, dev), to_clip(x[:, c:], dtype, dev), to_clip(raw, dtype, dev),
+                      f1.to(dev), f2.to(dev), wp, b.to(dev), c)
+    torch.cuda.synchronize()
+    assert_close(from_clip(y), ref, dtype, f"dcn c={c}", scale=2.0)
+
+
+def test_embedding_linear_layout(dev):
+    from oracle.unet import timestep_embedding
+    ops = _ops()
+    g = torch.Generator().manual_seed(2)
+    t = torch.tensor([0., 1., 37., 999., 500.5])
+    ref = timestep_embedding(t, 128)
+    y = ops.timestep_embedding(t.to(dev), 128)
+    assert_close(y.cpu(), ref, torch.float32, "timestep_embedding", scale=50.0)
+    x = torch.randn(16, 512, generator=g)
+    w = torch.randn(1000, 512, generator=g) / 22
+    b = torch.randn(1000, generator=g)
+    ref = F.linear(F.silu(x), w, b)
+    y = ops.linear(x.to(dev), w.to(dev), b.to(dev), act_in=ops.ACT_SILU)
+    assert_close(y.cpu(), ref, torch.float32, "linear")
+    img = torch.randn(4, 3, 10, 6, generator=g)
+    for dt in DTYPES:
+        clip = torch.zeros(4, 10, 6, 32, dtype=dt, device=dev)
+        ops.nchw_to_clip(img.to(dev), clip, coff=3)
+        back = ops.clip_to_nchw(clip, 3, coff=3)
+        assert_close(back.cpu(), rb(img, dt), dt, "layout")
+        assert clip[..., :3].abs().sum().item() == 0 and clip[..., 6:].abs().sum().item() == 0
+
+
+def test_error_paths(dev):
+    from flair_amd import _lib, ops
+    x = torch.zeros(1, 4, 4, 24, dtype=torch.bfloat16, device=dev)
+    w = torch.zeros(8, 9, 24, dtype=torch.bfloat16, device=dev)
+    with pytest.raises(_lib.FlairHipError, match="multiple of 32"):
+        ops.conv(x, w, None, 8, (1, 3, 3))
+    with pytest.raises(_lib.FlairHipError):
+        ops.conv(torch.zeros(1, 4, 4, 32), torch.zeros(8, 9, 32), None, 8, (1, 3, 3))  # CPU tensors
