@@ -119,10 +119,11 @@ __global__ void sampler_update_kernel(const float* x, float* x0, const float* re
     }
 }
 
-// generic: out = a*x + b*y  (f32, flat)
-__global__ void axpby_kernel(const float* x, const float* y, float a, float b, long n, float* out) {
+// generic: out = clamp(a*x + b*y, lo, hi)  (f32, flat)
+__global__ void axpby_kernel(const float* x, const float* y, float a, float b, float lo, float hi, long n,
+                             float* out) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-        out[i] = a * x[i] + (y ? b * y[i] : 0.f);
+        out[i] = fminf(fmaxf(a * x[i] + (y ? b * y[i] : 0.f), lo), hi);
 }
 
 // per-pixel multiply of an NHWC tensor by a [pixels] f32 map (BasicVSR++ vsrpp_weights)
@@ -281,10 +282,10 @@ extern "C" int flair_sampler_update(const flair_sampler_coefs* c, const float* x
     return FLAIR_OK;
 }
 
-extern "C" int flair_axpby_f32(const float* x, const float* y, float a, float b, long n, float* out,
-                               hipStream_t stream) {
+extern "C" int flair_axpby_f32(const float* x, const float* y, float a, float b, float lo, float hi, long n,
+                               float* out, hipStream_t stream) {
     FLAIR_CHECK(x && out && n > 0, "flair_axpby_f32: bad argument");
-    hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, y, a, b, n, out);
+    hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, y, a, b, lo, hi, n, out);
     FLAIR_LAUNCH_CHECK();
     return FLAIR_OK;
 }
@@ -341,6 +342,34 @@ extern "C" int flair_cast_channels(const float* src, int src_ld, int C, long P, 
                            (float*)dst, dst_ld, dst_coff);
     else
         FLAIR_CHECK(false, "flair_cast_channels: bad dtype");
+    FLAIR_LAUNCH_CHECK();
+    return FLAIR_OK;
+}
+
+namespace {
+// LEARNED_RANGE variance (gaussian_diffusion.py:285-292): frac=(v+1)/2,
+// logvar = frac*max_log + (1-frac)*min_log, var = exp(logvar); v = channels [C,2C) of the model output.
+__global__ void learned_range_kernel(const float* modelOut, int N, int C, long HW, float minLog, float maxLog,
+                                     float* var, float* logvar) {
+    const long total = (long)N * C * HW;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long n = i / (C * HW), r = i % (C * HW);
+        const float v = modelOut[(n * 2 * C + C) * HW + r];
+        const float frac = (v + 1.f) / 2.f;
+        const float lv = frac * maxLog + (1.f - frac) * minLog;
+        logvar[i] = lv;
+        var[i] = expf(lv);
+    }
+}
+}  // namespace
+
+extern "C" int flair_learned_range_variance(const float* model_out, int N, int C, int H, int W, float min_log,
+                                            float max_log, float* variance, float* log_variance,
+                                            hipStream_t stream) {
+    FLAIR_CHECK(model_out && variance && log_variance && N > 0 && C > 0, "flair_learned_range_variance: bad argument");
+    const long HW = (long)H * W;
+    hipLaunchKernelGGL(learned_range_kernel, dim3(grid_for((long)N * C * HW)), dim3(256), 0, stream, model_out, N, C,
+                       HW, min_log, max_log, variance, log_variance);
     FLAIR_LAUNCH_CHECK();
     return FLAIR_OK;
 }

@@ -94,7 +94,7 @@ __device__ __forceinline__ float cubic1(float x, float A) { return ((A + 2.f) * 
 __device__ __forceinline__ float cubic2(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
 
 // mode: 0 bilinear align_corners=False, 1 bilinear align_corners=True, 2 bicubic
-// (align_corners=False, A=-0.75, border-clamped taps), 3 2x2 average pool.
+// (align_corners=False, A=-0.75, border-clamped taps), 3 2x2 average pool, 4 nearest.
 template <typename E>
 __global__ void resize_kernel(const E* x, int xLd, int F, int Hi, int Wi, int C, int mode, int Ho, int Wo, E* y,
                               int yLd, float outScaleX, float outScaleY) {
@@ -107,7 +107,13 @@ __global__ void resize_kernel(const E* x, int xLd, int F, int Hi, int Wi, int C,
         const long f = p / ((long)Wo * Ho);
         const E* fb = x + f * Hi * Wi * xLd + c;
         float r = 0.f;
-        if (mode == 3) {
+        if (mode == 4) {  // nearest (F.interpolate default): src = floor(dst * in/out)
+            int yy = (int)floorf((float)ho * ((float)Hi / (float)Ho));
+            int xx = (int)floorf((float)wo * ((float)Wi / (float)Wo));
+            yy = yy > Hi - 1 ? Hi - 1 : yy;
+            xx = xx > Wi - 1 ? Wi - 1 : xx;
+            r = ET<E>::ld(fb + ((long)yy * Wi + xx) * xLd);
+        } else if (mode == 3) {
             for (int q = 0; q < 4; ++q)
                 r += ET<E>::ld(fb + ((long)(2 * ho + (q >> 1)) * Wi + 2 * wo + (q & 1)) * xLd);
             r *= 0.25f;
@@ -193,7 +199,7 @@ extern "C" int flair_flow_compose(const float* f1, const float* f2, int F, int H
 
 extern "C" int flair_resize_nhwc(const void* x, int dtype, int x_ld, int F, int Hi, int Wi, int C, int mode, int Ho,
                                  int Wo, void* y, int y_ld, float scale_c0, float scale_c1, hipStream_t stream) {
-    FLAIR_CHECK(x && y && F > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0 && mode >= 0 && mode <= 3,
+    FLAIR_CHECK(x && y && F > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0 && mode >= 0 && mode <= 4,
                 "flair_resize_nhwc: bad argument");
     FLAIR_CHECK(mode != 3 || (Hi == 2 * Ho && Wi == 2 * Wo), "flair_resize_nhwc: avg-pool needs exact 2x");
     const long n = (long)F * Ho * Wo * C;

@@ -1,0 +1,768 @@
+"""FLAIR's video UNet (gaussian / jpeg tasks) executed by hand-written gfx950 kernels.
+
+Python surface of the reference's ``guided_diffusion/unet_new.py`` (``UNetModel`` with the
+same constructor arguments, ``forward`` keyword arguments, ``convert_to_fp16/32`` and
+state-dict names, unet_new.py:901-1362), re-designed for MI355X:
+
+  * activations are NHWC "clip tensors" (T, H, W, C) resident in HBM for the whole
+    forward; the reference's LazyReshaper2D/3D transposes (nn.py:350-367) and every
+    ``th.cat`` disappear (convs read up to four channel segments directly);
+  * every layer is one or a few calls into libflair_hip.so through ``flair_amd.ops``
+    (implicit-GEMM MFMA convs, fused GroupNorm+FiLM+SiLU(+resample), MFMA attention,
+    fused deformable alignment);
+  * all ``emb_layers`` linears of the network are evaluated in ONE launch per step;
+  * SPyNet optical flow is step-invariant (unet_new.py:1334-1348 recomputes it every
+    denoising step): it is computed once per clip and cached;
+  * reduced precision is bfloat16 (``convert_to_fp16`` selects it; the reference's fp16
+    is the CUDA-era choice).  GroupNorm statistics, embeddings, flows and SPyNet stay f32.
+
+``torch.nn`` modules here only hold parameters (names, shapes, default init); their
+``forward`` is never used.  There is no CPU path: tensors must be on ``cuda``.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .nn_new import conv_nd, linear, normalization, zero_module
+
+A = ops  # activation codes live there
+
+
+# ------------------------------------------------------------------------- containers
+class PlaceHolder(nn.Module):
+    """Keeps the reference's ``wrapped_module`` level in parameter names (nn.py:340-367)."""
+
+    def __init__(self, module):
+        super().__init__()
+        self.wrapped_module = module
+
+
+LazyReshaper2D = LazyReshaper3D = PlaceHolder
+
+
+class TemporalWrapper(PlaceHolder):
+    """unet_new.py:50-59 (skipped when ``enable_cross_frames`` is False)."""
+
+
+def _dev(p, device):
+    t = p.detach()
+    if t.device != device or t.dtype != torch.float32 or not t.is_contiguous():
+        t = t.to(device=device, dtype=torch.float32).contiguous()
+    return t
+
+
+class Ctx:
+    """Per-forward execution context."""
+
+    def __init__(self, dtype, device, T):
+        self.dtype, self.device, self.T = dtype, device, T
+        self.emb = None        # (T, 4*model_channels) f32
+        self.film_all = None   # (T, sum of emb_layers widths) f32
+        self.flows = {}
+        self.vsrpp_weights = None
+        self.enable_cross_frames = True
+
+
+def _pack(w, segs, dtype, device, cout_pad=None):
+    return ops.pack_conv_weight(w.detach().to(device), segs, dtype, cout_pad)
+
+
+# --------------------------------------------------------------------------- ResBlock
+class ResBlock(nn.Module):
+    """unet_new.py:198-329.  GroupNorm over the clip -> SiLU -> [2x resample] -> conv ->
+    GroupNorm * (1+scale) + shift -> SiLU -> conv, plus identity / 1x1 skip."""
+
+    def __init__(self, channels, emb_channels, dropout, out_channels=None, use_conv=False,
+                 use_scale_shift_norm=False, dims=2, use_checkpoint=False, up=False, down=False):
+        super().__init__()
+        if not use_scale_shift_norm:
+            raise NotImplementedError("flair_amd: only use_scale_shift_norm=True (the shipped "
+                                      "FLAIR configuration) is implemented")
+        if use_conv:
+            raise NotImplementedError("flair_amd: 3x3 skip convolutions are not used by FLAIR")
+        self.channels = channels
+        self.out_channels = out_channels or channels
+        self.dims, self.up, self.down = dims, up, down
+        self.in_layers = nn.Sequential(
+            PlaceHolder(normalization(channels)), nn.SiLU(),
+            PlaceHolder(conv_nd(dims, channels, self.out_channels, 3, padding=1)))
+        self.emb_layers = nn.Sequential(nn.SiLU(), linear(emb_channels, 2 * self.out_channels))
+        self.out_layers = nn.Sequential(
+            PlaceHolder(normalization(self.out_channels)), nn.SiLU(), nn.Dropout(p=dropout),
+            zero_module(PlaceHolder(conv_nd(dims, self.out_channels, self.out_channels, 3, padding=1))))
+        if self.out_channels == channels:
+            self.skip_connection = nn.Identity()
+        else:
+            self.skip_connection = PlaceHolder(conv_nd(dims, channels, self.out_channels, 1))
+        self.film_off = 0
+        self._pk = None
+
+    def pack(self, dtype, device, split=None):
+        """split: channel widths of the (implicitly concatenated) input segments."""
+        c, co = self.channels, self.out_channels
+        segs = [(s, s) for s in (split or [c])]
+        self._pk = dict(
+            w1=_pack(self.in_layers[2].wrapped_module.weight, [(c, c)], dtype, device),
+            b1=_dev(self.in_layers[2].wrapped_module.bias, device),
+            w2=_pack(self.out_layers[3].wrapped_module.weight, [(co, co)], dtype, device),
+            b2=_dev(self.out_layers[3].wrapped_module.bias, device),
+            g1=_dev(self.in_layers[0].wrapped_module.weight, device),
+            be1=_dev(self.in_layers[0].wrapped_module.bias, device),
+            g2=_dev(self.out_layers[0].wrapped_module.weight, device),
+            be2=_dev(self.out_layers[0].wrapped_module.bias, device))
+        if not isinstance(self.skip_connection, nn.Identity):
+            self._pk["ws"] = _pack(self.skip_connection.wrapped_module.weight, segs, dtype, device)
+            self._pk["bs"] = _dev(self.skip_connection.wrapped_module.bias, device)
+
+    def run(self, ctx, x, x1=None):
+        pk = self._pk
+        co = self.out_channels
+        k = (1, 3, 3) if self.dims == 2 else (3, 3, 3)
+        film = ctx.film_all[:, self.film_off:self.film_off + 2 * co]
+        eps = self.in_layers[0].wrapped_module.eps
+        if self.up or self.down:
+            assert x1 is None
+            h, x = ops.group_norm(x, pk["g1"], pk["be1"], eps=eps, act=A.ACT_SILU,
+                                  resample=2 if self.up else 1, want_raw=True)
+        else:
+            h = ops.group_norm(x, pk["g1"], pk["be1"], x1=x1, eps=eps, act=A.ACT_SILU)
+        h = ops.conv(h, pk["w1"], pk["b1"], co, k)
+        h = ops.group_norm(h, pk["g2"], pk["be2"], eps=eps, act=A.ACT_SILU, film=film)
+        if "ws" in pk:
+            skip = ops.conv([x] if x1 is None else [x, x1], pk["ws"], pk["bs"], co, (1, 1, 1))
+        else:
+            assert x1 is None
+            skip = x
+        return ops.conv(h, pk["w2"], pk["b2"], co, k, res0=skip)
+
+
+# -------------------------------------------------------------------------- attention
+class QKVAttentionLegacy(nn.Module):
+    """unet_new.py:540-570 -- layout marker; executed by ops.qkv_attention."""
+
+    def __init__(self, n_heads):
+        super().__init__()
+        self.n_heads = n_heads
+
+
+class QKVAttention(QKVAttentionLegacy):
+    """unet_new.py:573-605."""
+
+
+class AttentionBlock(nn.Module):
+    """unet_new.py:332-377."""
+
+    bottleneck = False
+
+    def __init__(self, channels, num_heads=1, num_head_channels=-1, use_checkpoint=False,
+                 use_new_attention_order=False):
+        super().__init__()
+        self.channels = channels
+        if num_head_channels == -1:
+            self.num_heads = num_heads
+        else:
+            assert channels % num_head_channels == 0
+            self.num_heads = channels // num_head_channels
+        if self.bottleneck:
+            self.emb_layers = nn.Sequential(nn.SiLU(), linear(512, 512))
+        self.norm = PlaceHolder(normalization(channels))
+        self.qkv = conv_nd(1, channels, channels * 3, 1)
+        self.attention = (QKVAttention if use_new_attention_order else QKVAttentionLegacy)(self.num_heads)
+        self.new_order = use_new_attention_order
+        self.proj_out = zero_module(conv_nd(1, channels, channels, 1))
+        self.film_off = 0
+        self._pk = None
+
+    def pack(self, dtype, device):
+        c = self.channels
+        self._pk = dict(
+            g=_dev(self.norm.wrapped_module.weight, device), be=_dev(self.norm.wrapped_module.bias, device),
+            wqkv=_pack(self.qkv.weight.unsqueeze(-1), [(c, c)], dtype, device), bqkv=_dev(self.qkv.bias, device),
+            wp=_pack(self.proj_out.weight.unsqueeze(-1), [(c, c)], dtype, device),
+            bp=_dev(self.proj_out.bias, device))
+
+    def run(self, ctx, x):
+        pk, c = self._pk, self.channels
+        n = ops.group_norm(x, pk["g"], pk["be"], eps=self.norm.wrapped_module.eps)
+        qkv = ops.conv(n, pk["wqkv"], pk["bqkv"], 3 * c, (1, 1, 1))
+        a = ops.qkv_attention(qkv, self.num_heads, new_order=self.new_order)
+        if self.bottleneck:
+            ops.add_frame_bias(a, ctx.film_all[:, self.film_off:self.film_off + c])
+        return ops.conv(a, pk["wp"], pk["bp"], c, (1, 1, 1), res0=x)
+
+
+class AttentionbottleBlock(AttentionBlock):
+    """unet_new.py:380-429: adds SiLU->Linear(512,512)(emb) to the attention output."""
+
+    bottleneck = True
+
+
+class FalshAttn(nn.Module):
+    """nn.py:389-394 -- marker only (the window attention kernel replaces flash-attn)."""
+
+
+class TemporalAttention(nn.Module):
+    """unet_new.py:432-517."""
+
+    def __init__(self, channels, num_frames, num_heads=1, num_head_channels=-1, use_checkpoint=False):
+        super().__init__()
+        self.channels = channels
+        if num_head_channels == -1:
+            self.num_heads = num_heads
+        else:
+            assert channels % num_head_channels == 0
+            self.num_heads = channels // num_head_channels
+        assert num_frames % 2 == 1, "num_frames must be odd"
+        if channels // self.num_heads != 64:
+            raise NotImplementedError("flair_amd: temporal attention head width must be 64")
+        self.num_frames = num_frames
+        self.q_linear = linear(channels, channels)
+        self.k_linear = linear(channels, channels)
+        self.v_linear = linear(channels, channels)
+        self.attn = FalshAttn()
+        self.proj = zero_module(PlaceHolder(conv_nd(2, channels, channels, 1)))
+        self.norm = PlaceHolder(normalization(channels))
+        self._pk = None
+
+    def pack(self, dtype, device):
+        c, f = self.channels, self.num_frames
+        # positional codes of the window offsets and their images under W_q / W_k are
+        # constants of the layer: fold them once (q bias, per-slot key bias).
+        offs = torch.arange(f, dtype=torch.float32, device=device) - f // 2
+        pe = ops.timestep_embedding(offs, c)
+        mid = f // 2
+        wq, wk, wv = (_dev(m.weight, device) for m in (self.q_linear, self.k_linear, self.v_linear))
+        bq = ops.linear(pe[mid:mid + 1].contiguous(), wq, _dev(self.q_linear.bias, device))
+        kpos = ops.linear(torch.cat([pe[:mid], pe[mid + 1:]]).contiguous(), wk, None)
+        wqkv = torch.cat([wq, wk, wv]).reshape(3 * c, c, 1, 1)
+        bqkv = torch.cat([bq.reshape(-1), _dev(self.k_linear.bias, device), _dev(self.v_linear.bias, device)])
+        self._pk = dict(
+            g=_dev(self.norm.wrapped_module.weight, device), be=_dev(self.norm.wrapped_module.bias, device),
+            wqkv=_pack(wqkv, [(c, c)], dtype, device), bqkv=bqkv.contiguous(), kpos=kpos,
+            wp=_pack(self.proj.wrapped_module.weight, [(c, c)], dtype, device),
+            bp=_dev(self.proj.wrapped_module.bias, device))
+
+    def run(self, ctx, h):
+        pk, c = self._pk, self.channels
+        n = ops.group_norm(h, pk["g"], pk["be"], eps=self.norm.wrapped_module.eps)
+        qkv = ops.conv(n, pk["wqkv"], pk["bqkv"], 3 * c, (1, 1, 1))
+        a = ops.temporal_attention(qkv, pk["kpos"], self.num_frames,
+                                   round_fp16=(ctx.dtype == torch.float32))
+        return ops.conv(a, pk["wp"], pk["bp"], c, (1, 1, 1), res0=h)
+
+
+# ------------------------------------------------------------------------- BasicVSR++
+class ResidualBlockNoBN(nn.Module):
+    def __init__(self, mid_channels):
+        super().__init__()
+        self.conv1 = nn.Conv2d(mid_channels, mid_channels, 3, 1, 1, bias=True)
+        self.conv2 = nn.Conv2d(mid_channels, mid_channels, 3, 1, 1, bias=True)
+
+
+class ResidualBlocksWithInputConv(nn.Module):
+    """mmedit container (names ``main.0``, ``main.2.<i>.conv1/conv2``); one block is used."""
+
+    def __init__(self, in_channels, out_channels=64, num_blocks=1):
+        super().__init__()
+        if num_blocks != 1:
+            raise NotImplementedError("flair_amd: FLAIR uses one residual block per trunk")
+        self.main = nn.Sequential(nn.Conv2d(in_channels, out_channels, 3, 1, 1, bias=True),
+                                  nn.LeakyReLU(negative_slope=0.1),
+                                  nn.Sequential(ResidualBlockNoBN(out_channels)))
+
+    def pack(self, dtype, device, split):
+        c = self.main[0].out_channels
+        rb = self.main[2][0]
+        return dict(w0=_pack(self.main[0].weight, [(s, s) for s in split], dtype, device),
+                    b0=_dev(self.main[0].bias, device),
+                    w1=_pack(rb.conv1.weight, [(c, c)], dtype, device), b1=_dev(rb.conv1.bias, device),
+                    w2=_pack(rb.conv2.weight, [(c, c)], dtype, device), b2=_dev(rb.conv2.bias, device))
+
+
+def run_trunk(pk, segs, c, *, extra_res=None, out=None, out_scale=1.0):
+    """conv3x3+LeakyReLU -> x + conv(relu(conv(x))) [+ extra_res], scaled."""
+    k = (1, 3, 3)
+    t1 = ops.conv(segs, pk["w0"], pk["b0"], c, k, act=A.ACT_LRELU01)
+    t2 = ops.conv(t1, pk["w1"], pk["b1"], c, k, act=A.ACT_RELU)
+    return ops.conv(t2, pk["w2"], pk["b2"], c, k, res0=t1, res1=extra_res, out=out, out_scale=out_scale)
+
+
+class SecondOrderDeformableAlignment(nn.Module):
+    """unet_new.py:835-898 (mmcv ModulatedDeformConv2d parameters + conv_offset stack)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, padding=1, deform_groups=16,
+                 max_residue_magnitude=10):
+        super().__init__()
+        assert kernel_size == 3 and padding == 1
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.deform_groups, self.max_residue_magnitude = deform_groups, max_residue_magnitude
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, 3, 3))
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+        stdv = 1.0 / math.sqrt(in_channels * 9)
+        with torch.no_grad():
+            self.weight.uniform_(-stdv, stdv)
+        c = out_channels
+        self.conv_offset = nn.Sequential(
+            nn.Conv2d(3 * c + 4, c, 3, 1, 1), nn.LeakyReLU(negative_slope=0.1),
+            nn.Conv2d(c, c, 3, 1, 1), nn.LeakyReLU(negative_slope=0.1),
+            nn.Conv2d(c, c, 3, 1, 1), nn.LeakyReLU(negative_slope=0.1),
+            nn.Conv2d(c, 27 * deform_groups, 3, 1, 1))
+        zero_module(self.conv_offset[-1])
+
+    def pack(self, dtype, device):
+        c = self.out_channels
+        ka = ops.k_align(dtype)
+        co = self.conv_offset
+        return dict(
+            w0=_pack(co[0].weight, [(c, c), (c, c), (c, c), (4, ka)], dtype, device), b0=_dev(co[0].bias, device),
+            w2=_pack(co[2].weight, [(c, c)], dtype, device), b2=_dev(co[2].bias, device),
+            w4=_pack(co[4].weight, [(c, c)], dtype, device), b4=_dev(co[4].bias, device),
+            w6=_pack(co[6].weight, [(c, c)], dtype, device), b6=_dev(co[6].bias, device),
+            wd=_pack(self.weight, [(2 * c, 2 * c)], dtype, device), bd=_dev(self.bias, device))
+
+
+class BasicVSRPP(nn.Module):
+    """unet_new.py:608-832: backward then forward second-order propagation over the frames
+    (a batch-1 recurrence), then a clip-wide reconstruction trunk, 1x1 conv and residual."""
+
+    def __init__(self, mid_channels=64, max_residue_magnitude=10, use_checkpoint=False):
+        super().__init__()
+        self.mid_channels = mid_channels
+        self.deform_align = nn.ModuleDict()
+        self.backbone = nn.ModuleDict()
+        for i, name in enumerate(["backward_1", "forward_1"]):
+            self.deform_align[name] = SecondOrderDeformableAlignment(
+                2 * mid_channels, mid_channels, 3, padding=1, deform_groups=16,
+                max_residue_magnitude=max_residue_magnitude)
+            self.backbone[name] = ResidualBlocksWithInputConv((2 + i) * mid_channels, mid_channels, 1)
+        self.reconstruction = ResidualBlocksWithInputConv(3 * mid_channels, mid_channels, 1)
+        self.conv_last = zero_module(nn.Conv2d(mid_channels, mid_channels, 1, 1))
+        self._pk = None
+
+    def pack(self, dtype, device):
+        c = self.mid_channels
+        self._pk = dict(
+            align={n: m.pack(dtype, device) for n, m in self.deform_align.items()},
+            trunk={"backward_1": self.backbone["backward_1"].pack(dtype, device, [c, c]),
+                   "forward_1": self.backbone["forward_1"].pack(dtype, device, [c, c, c])},
+            recon=self.reconstruction.pack(dtype, device, [c, c, c]),
+            wl=_pack(self.conv_last.weight, [(c, c)], dtype, device), bl=_dev(self.conv_last.bias, device))
+
+    def _propagate(self, ctx, hidden, flows, name, others, weight, wmaps, dest):
+        """others: list of (T,H,W,c) feature stacks of earlier branches; dest: (T,H,W,c)
+        stack receiving this branch's per-frame features."""
+        pk_a, pk_t = self._pk["align"][name], self._pk["trunk"][name]
+        T, H, W, c = hidden.shape
+        order = list(range(T))
+        flow_idx = list(range(-1, T - 1))
+        if "backward" in name:
+            order = order[::-1]
+            flow_idx = order
+        zero_c = torch.zeros((1, H, W, c), dtype=ctx.dtype, device=ctx.device)
+        ka = ops.k_align(ctx.dtype)
+        flowpad = torch.zeros((1, H, W, ka), dtype=ctx.dtype, device=ctx.device)
+        k3 = (1, 3, 3)
+        G = self.deform_align[name].deform_groups
+        mag = float(self.deform_align[name].max_residue_magnitude)
+        prop, prev2 = zero_c, None     # prop: feature of the previous step; prev2: the one before
+        for i, idx in enumerate(order):
+            cur = hidden[idx:idx + 1]
+            if i > 0:
+                flow_n1 = flows[flow_idx[i]:flow_idx[i] + 1]
+                cond_n1 = ops.flow_warp(prop, flow_n1)
+                if i > 1:
+                    feat_n2 = prev2
+                    flow_n2 = ops.flow_compose(flow_n1, flows[flow_idx[i - 1]:flow_idx[i - 1] + 1])
+                    cond_n2 = ops.flow_warp(feat_n2, flow_n2)
+                    ops.cast_channels(flow_n2, flowpad, 2)
+                else:
+                    feat_n2, flow_n2, cond_n2 = zero_c, None, zero_c
+                ops.cast_channels(flow_n1, flowpad, 0)
+                o = ops.conv([cond_n1, cur, cond_n2, flowpad], pk_a["w0"], pk_a["b0"], c, k3, act=A.ACT_LRELU01)
+                o = ops.conv(o, pk_a["w2"], pk_a["b2"], c, k3, act=A.ACT_LRELU01)
+                o = ops.conv(o, pk_a["w4"], pk_a["b4"], c, k3, act=A.ACT_LRELU01)
+                raw = ops.conv(o, pk_a["w6"], pk_a["b6"], 27 * G, k3)
+                aligned = ops.dcn_align(prop, feat_n2, raw, flow_n1, flow_n2, pk_a["wd"], pk_a["bd"], c,
+                                        groups=G, max_mag=mag)
+            else:
+                aligned = zero_c
+            segs = [cur] + [o_[idx:idx + 1] for o_ in others] + [aligned]
+            new = run_trunk(pk_t, segs, c, extra_res=aligned, out=dest[idx:idx + 1], out_scale=weight)
+            if wmaps is not None:
+                ops.scale_pixels(new, wmaps[idx])
+            prev2, prop = (prop if i > 0 else None), new
+        return dest
+
+    def run(self, ctx, hidden):
+        T, H, W, c = hidden.shape
+        flows_forward, flows_backward = ctx.flows[W]
+        weight, wmaps = 1.0, None
+        vw = ctx.vsrpp_weights
+        if isinstance(vw, (float, int)):
+            weight = float(vw)
+        elif vw is not None:          # (T,1,h,w) f32 map -> nearest resize to this level
+            wm = vw.reshape(T, vw.shape[-2], vw.shape[-1], 1).float().contiguous()
+            if wm.shape[1] != H or wm.shape[2] != W:
+                wm = ops.resize(wm, (H, W), ops.RESIZE_NEAREST)
+            wmaps = [wm[i] for i in range(T)]
+        bwd = torch.empty_like(hidden)
+        fwd = torch.empty_like(hidden)
+        self._propagate(ctx, hidden, flows_backward, "backward_1", [], weight, wmaps, bwd)
+        ff = flows_forward if flows_forward is not None else flows_backward.flip(0)
+        self._propagate(ctx, hidden, ff, "forward_1", [bwd], weight, wmaps, fwd)
+        rec = run_trunk(self._pk["recon"], [hidden, bwd, fwd], c)
+        return ops.conv(rec, self._pk["wl"], self._pk["bl"], c, (1, 1, 1), res0=hidden)
+
+
+# ----------------------------------------------------------------------------- SPyNet
+class _ConvModule(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, kernel_size=7, stride=1, padding=3)
+
+
+class SPyNetBasicModule(nn.Module):
+    def __init__(self):
+        super().__init__()
+        ch = [8, 32, 64, 32, 16, 2]
+        self.basic_module = nn.Sequential(*[_ConvModule(ch[i], ch[i + 1]) for i in range(5)])
+
+
+class SPyNet(nn.Module):
+    """mmedit SPyNet parameters (``basic_module.<l>.basic_module.<j>.conv``) + HIP execution
+    in f32: 5 avg-pool pyramid levels, per level bilinear x2 flow upsampling, border warp
+    and five 7x7 convs.  Works on NHWC f32 with the 8 input channels laid out as
+    [ref 0-2 | 0 | warped 4-6 | 0 | flow 8-9 | 0...] (16 channels, one K step)."""
+
+    def __init__(self, pretrained=None):
+        super().__init__()
+        self.basic_module = nn.ModuleList([SPyNetBasicModule() for _ in range(6)])
+        self.register_buffer("mean", torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1))
+        self.register_buffer("std", torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1))
+        self._pk = None
+
+    def pack(self, device):
+        f32 = torch.float32
+        levels = []
+        for bm in self.basic_module:
+            convs = [m.conv for m in bm.basic_module]
+            ws = [_pack(convs[0].weight, [(3, 4), (3, 4), (2, 8)], f32, device)]
+            ws += [_pack(convs[j].weight, [(convs[j].in_channels,) * 2], f32, device) for j in (1, 2, 3)]
+            ws.append(_pack(convs[4].weight, [(16, 16)], f32, device, cout_pad=4))
+            bs = [_dev(convs[j].bias, device) for j in range(4)]
+            bs.append(torch.cat([_dev(convs[4].bias, device), torch.zeros(2, device=device)]).contiguous())
+            levels.append((ws, bs))
+        mean = _dev(self.mean.reshape(-1), device)
+        istd = (1.0 / _dev(self.std.reshape(-1), device)).contiguous()
+        self._pk = dict(levels=levels, mean=mean, istd=istd)
+
+    def run(self, ref, supp):
+        """ref, supp: (F,h,w,4) f32 normalised frames (channel 3 zero) -> (F,h,w,2) flow."""
+        F_, h0, w0, _ = ref.shape
+        dev = ref.device
+        h = h0 if h0 % 32 == 0 else 32 * (h0 // 32 + 1)
+        w = w0 if w0 % 32 == 0 else 32 * (w0 // 32 + 1)
+        if (h, w) != (h0, w0):
+            ref = ops.resize(ref, (h, w), ops.RESIZE_BILINEAR, channels=3)
+            supp = ops.resize(supp, (h, w), ops.RESIZE_BILINEAR, channels=3)
+        sizes = [(h >> (5 - l), w >> (5 - l)) for l in range(6)]
+        bufs = [torch.zeros((F_, *sizes[l], 16), dtype=torch.float32, device=dev) for l in range(6)]
+        sp = [None] * 6
+        ops.cast_channels(ref[..., :3], bufs[5], 0)
+        sp[5] = supp
+        for l in range(4, -1, -1):
+            ops.resize(bufs[l + 1][..., 0:4], sizes[l], ops.RESIZE_AVGPOOL2, channels=3, out=bufs[l][..., 0:4])
+            sp[l] = ops.resize(sp[l + 1], sizes[l], ops.RESIZE_AVGPOOL2, channels=3)
+        flow = None
+        k7 = (1, 7, 7)
+        for l in range(6):
+            b = bufs[l]
+            if l > 0:
+                ops.resize(flow, sizes[l], ops.RESIZE_BILINEAR_AC, channels=2, out=b[..., 8:12],
+                           scale_c0=2.0, scale_c1=2.0)
+            ops.flow_warp(sp[l], b[..., 8:10], border=True, out=b[..., 4:8])
+            ws, bs = self._pk["levels"][l]
+            y = ops.conv(b, ws[0], bs[0], 32, k7, act=A.ACT_RELU)
+            y = ops.conv(y, ws[1], bs[1], 64, k7, act=A.ACT_RELU)
+            y = ops.conv(y, ws[2], bs[2], 32, k7, act=A.ACT_RELU)
+            y = ops.conv(y, ws[3], bs[3], 16, k7, act=A.ACT_RELU)
+            flow = ops.conv(y, ws[4], bs[4], 4, k7, res0=b[..., 8:12])
+        out = torch.empty((F_, h0, w0, 2), dtype=torch.float32, device=dev)
+        ops.resize(flow, (h0, w0), ops.RESIZE_BILINEAR, channels=2, out=out,
+                   scale_c0=float(w0) / float(w), scale_c1=float(h0) / float(h))
+        return out
+
+
+# ------------------------------------------------------------------------------ stages
+class TimestepEmbedSequential(nn.Sequential):
+    """unet_new.py:106-133: routes (emb, flows, weights) by layer type."""
+
+    def run(self, ctx, h, skip=None):
+        for i, layer in enumerate(self):
+            inner = layer.wrapped_module if isinstance(layer, PlaceHolder) else layer
+            if isinstance(layer, TemporalWrapper) and not ctx.enable_cross_frames:
+                continue
+            if isinstance(inner, ResBlock):
+                h = inner.run(ctx, h, skip if i == 0 else None)
+            elif isinstance(inner, (AttentionBlock, TemporalAttention, BasicVSRPP)):
+                h = inner.run(ctx, h)
+            elif isinstance(inner, nn.Conv2d):      # the stem
+                h = ops.conv(h, inner._pk_w, inner._pk_b, inner.out_channels, (1, 3, 3))
+            elif isinstance(inner, nn.Identity):
+                pass
+            else:
+                raise TypeError(f"flair_amd: no executor for {type(inner).__name__}")
+        return h
+
+
+class UNetModel(nn.Module):
+    """unet_new.py:901-1362 (same arguments; ``use_fp16`` / ``convert_to_fp16`` select bf16)."""
+
+    def __init__(self, image_size, in_channels, model_channels, out_channels, num_res_blocks,
+                 attention_resolutions, rnn_resolutions, dropout=0, channel_mult=(1, 2, 4, 8),
+                 conv_resample=True, dims=2, num_classes=None, use_checkpoint=False, use_fp16=False,
+                 num_heads=1, num_head_channels=-1, num_heads_upsample=-1, use_scale_shift_norm=False,
+                 resblock_updown=False, use_new_attention_order=False, temporal_block=False):
+        super().__init__()
+        if dims != 2 or num_classes is not None or not resblock_updown:
+            raise NotImplementedError("flair_amd: UNetModel covers the FLAIR video configuration "
+                                      "(dims=2, resblock_updown=True, no class conditioning)")
+        if num_heads_upsample == -1:
+            num_heads_upsample = num_heads
+        self.image_size, self.in_channels, self.model_channels = image_size, in_channels, model_channels
+        self.out_channels, self.num_res_blocks = out_channels, num_res_blocks
+        self.attention_resolutions, self.rnn_resolutions = attention_resolutions, rnn_resolutions
+        self.channel_mult = channel_mult
+        self.dtype = torch.bfloat16 if use_fp16 else torch.float32
+        self.need_flows_res = [image_size // s for s in rnn_resolutions]
+
+        ted = model_channels * 4
+        self.time_embed = nn.Sequential(linear(model_channels, ted), nn.SiLU(), linear(ted, ted))
+        self.spynet = SPyNet(pretrained=None)
+
+        def res(cin, cout, d=2, **kw):
+            return ResBlock(cin, ted, dropout, out_channels=cout, dims=d, use_checkpoint=use_checkpoint,
+                            use_scale_shift_norm=use_scale_shift_norm, **kw)
+
+        def level_layers(cin, cout, ds, heads):
+            layers = [res(cin, cout)]
+            if temporal_block:
+                layers.append(TemporalWrapper(res(cout, cout, 3)))
+            if ds in attention_resolutions:
+                layers.append(AttentionBlock(cout, use_checkpoint=use_checkpoint, num_heads=heads,
+                                             num_head_channels=num_head_channels,
+                                             use_new_attention_order=use_new_attention_order))
+                if temporal_block:
+                    layers.append(TemporalWrapper(TemporalAttention(cout, 5, heads, num_head_channels,
+                                                                    use_checkpoint)))
+            if ds in rnn_resolutions and temporal_block:
+                layers.append(TemporalWrapper(BasicVSRPP(mid_channels=cout, use_checkpoint=use_checkpoint)))
+            return layers
+
+        ch = input_ch = int(channel_mult[0] * model_channels)
+        self.input_blocks = nn.ModuleList(
+            [TimestepEmbedSequential(LazyReshaper2D(conv_nd(dims, in_channels, ch, 3, padding=1)))])
+        chans, ds = [ch], 1
+        for level, mult in enumerate(channel_mult):
+            for _ in range(num_res_blocks):
+                cout = int(mult * model_channels)
+                self.input_blocks.append(TimestepEmbedSequential(*level_layers(ch, cout, ds, num_heads)))
+                ch = cout
+                chans.append(ch)
+            if level != len(channel_mult) - 1:
+                self.input_blocks.append(TimestepEmbedSequential(res(ch, ch, down=True)))
+                chans.append(ch)
+                ds *= 2
+        ident = nn.Identity
+        self.middle_block = TimestepEmbedSequential(
+            res(ch, ch),
+            TemporalWrapper(res(ch, ch, 3)) if temporal_block else ident(),
+            AttentionbottleBlock(ch, use_checkpoint=use_checkpoint, num_heads=num_heads,
+                                 num_head_channels=num_head_channels,
+                                 use_new_attention_order=use_new_attention_order),
+            TemporalWrapper(TemporalAttention(ch, 5, num_heads, num_head_channels, use_checkpoint))
+            if temporal_block else ident(),
+            res(ch, ch),
+            TemporalWrapper(res(ch, ch, 3)) if temporal_block else ident())
+        self._skip_split = []
+        self.output_blocks = nn.ModuleList([])
+        for level, mult in list(enumerate(channel_mult))[::-1]:
+            for i in range(num_res_blocks + 1):
+                ich = chans.pop()
+                cout = int(model_channels * mult)
+                layers = level_layers(ch + ich, cout, ds, num_heads_upsample)
+                self._skip_split.append((ch, ich))
+                ch = cout
+                if level and i == num_res_blocks:
+                    layers.append(res(ch, ch, up=True))
+                    ds //= 2
+                self.output_blocks.append(TimestepEmbedSequential(*layers))
+        self.out = nn.Sequential(LazyReshaper3D(normalization(ch)), nn.SiLU(),
+                                 zero_module(LazyReshaper2D(conv_nd(dims, input_ch, out_channels, 3, padding=1))))
+        self._packed_key = None
+        self._flow_cache = {}
+
+    # ---- dtype management (reference names) ------------------------------------------
+    def convert_to_fp16(self):
+        """Reference: fp16 torso (unet_new.py:1224-1238).  Here: bfloat16 kernels (f32
+        accumulate; GroupNorm statistics, embeddings, flows and SPyNet stay f32)."""
+        self.dtype = torch.bfloat16
+        self._packed_key = None
+
+    def convert_to_fp32(self):
+        self.dtype = torch.float32
+        self._packed_key = None
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self._packed_key = None
+        return out
+
+    def reset_flow_cache(self):
+        self._flow_cache = {}
+
+    # ---- weight packing ---------------------------------------------------------------
+    def _res_blocks(self):
+        for m in self.modules():
+            if isinstance(m, ResBlock):
+                yield m
+
+    def _ensure_packed(self, device):
+        key = (self.dtype, device)
+        if self._packed_key == key:
+            return
+        dt = self.dtype
+        ka = ops.k_align(dt)
+        stem = self.input_blocks[0][0].wrapped_module
+        stem._pk_w = _pack(stem.weight, [(self.in_channels, ops.pad_channels(self.in_channels, dt))], dt, device)
+        stem._pk_b = _dev(stem.bias, device)
+        # first ResBlock of every output stage reads (h | skip) as two segments
+        first_out = {id(st[0]): split for st, split in zip(self.output_blocks, self._skip_split)}
+        ws, bs, off = [], [], 0
+        for m in self.modules():
+            if isinstance(m, ResBlock):
+                m.pack(dt, device, list(first_out[id(m)]) if id(m) in first_out else None)
+            elif isinstance(m, (AttentionBlock, TemporalAttention, BasicVSRPP)):
+                m.pack(dt, device)
+            else:
+                continue
+            if isinstance(m, ResBlock) or getattr(m, "bottleneck", False):
+                lin = m.emb_layers[1]
+                m.film_off = off
+                ws.append(_dev(lin.weight, device))
+                bs.append(_dev(lin.bias, device))
+                off += lin.out_features
+        self._emb_w = torch.cat(ws).contiguous()
+        self._emb_b = torch.cat(bs).contiguous()
+        self.spynet.pack(device)
+        self._te = [_dev(p, device) for p in (self.time_embed[0].weight, self.time_embed[0].bias,
+                                               self.time_embed[2].weight, self.time_embed[2].bias)]
+        head = self.out[2].wrapped_module
+        cpad = (self.out_channels + 3) // 4 * 4
+        self._head_w = _pack(head.weight, [(head.in_channels,) * 2], dt, device, cout_pad=cpad)
+        self._head_b = torch.cat([_dev(head.bias, device),
+                                  torch.zeros(cpad - self.out_channels, device=device)]).contiguous()
+        self._head_g = _dev(self.out[0].wrapped_module.weight, device)
+        self._head_be = _dev(self.out[0].wrapped_module.bias, device)
+        self._packed_key = key
+        self._flow_cache = {}
+
+    # ---- optical flow (once per clip) --------------------------------------------------
+    def compute_flow(self, lqs):
+        """unet_new.py:1283-1309 on one clip; lqs: (T,3,h,w) f32 in [-1,1] ->
+        (flows_forward, flows_backward), each (T-1,h,w,2) f32 NHWC."""
+        T, _, h, w = lqs.shape
+        raw = torch.zeros((T, h, w, 4), dtype=torch.float32, device=lqs.device)
+        ops.nchw_to_clip(lqs.contiguous(), raw, 0)
+        return self._flows_from_clip(raw)
+
+    def _flows_from_clip(self, raw):
+        pk = self.spynet._pk
+        norm = torch.zeros_like(raw)
+        ops.affine_channels(raw, 3, 0.5, 0.5, 0.0, 1.0, pk["mean"], pk["istd"], norm)
+        a, b = norm[:-1], norm[1:]
+        flows_backward = self.spynet.run(a, b)
+        flows_forward = self.spynet.run(b, a)
+        return flows_forward, flows_backward
+
+    def _flows_for(self, rnn_clip):
+        """rnn_clip: (T,3,S,S) f32 device tensor.  Flows are a pure function of it, so they are
+        cached across the denoising steps of a clip (keyed on storage + version)."""
+        key = (rnn_clip.data_ptr(), rnn_clip._version, tuple(rnn_clip.shape))
+        hit = self._flow_cache.get(key)
+        if hit is None:
+            T, _, h, w = rnn_clip.shape
+            raw = torch.zeros((T, h, w, 4), dtype=torch.float32, device=rnn_clip.device)
+            ops.nchw_to_clip(rnn_clip.contiguous(), raw, 0)
+            flows = {}
+            for r in self.need_flows_res:
+                src = raw
+                if w != r:
+                    src = ops.resize(raw, (r, r), ops.RESIZE_BICUBIC, channels=3)
+                flows[r] = self._flows_from_clip(src)
+            if len(self._flow_cache) >= 16:
+                self._flow_cache.clear()
+            hit = (flows, rnn_clip)          # keep the keyed storage alive
+            self._flow_cache[key] = hit
+        return hit[0]
+
+    # ---- forward ----------------------------------------------------------------------
+    def forward(self, x, timesteps, low_res_input=None, num_frames=None, rnn_input=None,
+                enable_cross_frames=True, vsrpp_weights=None, **kwargs):
+        """Same contract as unet_new.py:1311-1362.  x: (B*T, C, H, W) f32 on the GPU;
+        low_res_input / rnn_input: (B, T, 3, H, W); returns (B*T, out_channels, H, W) f32.
+        Extra sampler kwargs (old_ts, sqrt_recip_alphas_cumprod, ...) are ignored."""
+        if not x.is_cuda:
+            raise RuntimeError("flair_amd.UNetModel runs on the MI355X only (tensors must be on "
+                               "'cuda'); there is no CPU path")
+        self._ensure_packed(x.device)
+        T = int(num_frames)
+        B = x.shape[0] // T
+        if rnn_input is None:
+            rnn_input = low_res_input
+        outs = []
+        for b in range(B):
+            vw = vsrpp_weights
+            if isinstance(vw, torch.Tensor):
+                vw = vw[b]
+            outs.append(self._forward_clip(x[b * T:(b + 1) * T].float().contiguous(),
+                                           timesteps[b * T:(b + 1) * T], low_res_input[b].float(),
+                                           rnn_input[b].float(), enable_cross_frames, vw))
+        return outs[0] if B == 1 else torch.cat(outs, dim=0)
+
+    def _forward_clip(self, x, t, low_res, rnn, enable_cross_frames, vsrpp_weights):
+        T, _, H, W = x.shape
+        dev, dt = x.device, self.dtype
+        ctx = Ctx(dt, dev, T)
+        ctx.enable_cross_frames = enable_cross_frames
+        ctx.vsrpp_weights = vsrpp_weights
+        ctx.flows = self._flows_for(rnn)
+        # timestep embedding MLP and every emb_layers linear of the network (f32)
+        temb = ops.timestep_embedding(t.float().contiguous(), self.model_channels)
+        e = ops.linear(temb, self._te[0], self._te[1], act_out=A.ACT_SILU)
+        ctx.emb = ops.linear(e, self._te[2], self._te[3])
+        ctx.film_all = ops.linear(ctx.emb, self._emb_w, self._emb_b, act_in=A.ACT_SILU)
+        # stem input: [x | low_res | 0...] as one K step of channels
+        cin = ops.pad_channels(self.in_channels, dt)
+        h = torch.zeros((T, H, W, cin), dtype=dt, device=dev)
+        ops.nchw_to_clip(x, h, 0)
+        ops.nchw_to_clip(low_res.contiguous(), h, x.shape[1])
+        hs = []
+        trace = getattr(self, "_trace", None)   # tests: per-stage activations
+        for i, blk in enumerate(self.input_blocks):
+            h = blk.run(ctx, h)
+            hs.append(h)
+            if trace is not None:
+                trace.append((f"input_blocks.{i}", h))
+        h = self.middle_block.run(ctx, h)
+        if trace is not None:
+            trace.append(("middle_block", h))
+        for i, blk in enumerate(self.output_blocks):
+            h = blk.run(ctx, h, hs.pop())
+            if trace is not None:
+                trace.append((f"output_blocks.{i}", h))
+        h = ops.group_norm(h, self._head_g, self._head_be, eps=self.out[0].wrapped_module.eps, act=A.ACT_SILU)
+        y = ops.conv(h, self._head_w, self._head_b, self._head_w.shape[0], (1, 3, 3))
+        return ops.clip_to_nchw(y, self.out_channels)

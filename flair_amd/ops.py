@@ -305,7 +305,7 @@ def flow_compose(f1, f2, out=None):
     return out
 
 
-RESIZE_BILINEAR, RESIZE_BILINEAR_AC, RESIZE_BICUBIC, RESIZE_AVGPOOL2 = 0, 1, 2, 3
+RESIZE_BILINEAR, RESIZE_BILINEAR_AC, RESIZE_BICUBIC, RESIZE_AVGPOOL2, RESIZE_NEAREST = 0, 1, 2, 3, 4
 
 
 def resize(x, size, mode, *, channels=None, out=None, scale_c0=1.0, scale_c1=1.0):
@@ -393,3 +393,24 @@ def cast_channels(src, dst, coff=0):
     check(lib().flair_cast_channels(ptr(src), _ld(src), C, ctypes.c_long(T * H * W), ptr(dst), dtype_code(dst),
                                     _ld(dst), coff, stream()), "flair_cast_channels")
     return dst
+
+
+def axpby(x, y, a, b, out=None, lo=float("-inf"), hi=float("inf")):
+    """out = clamp(a*x + b*y, lo, hi) on flat f32 tensors (y may be None)."""
+    assert x.dtype == torch.float32 and x.is_contiguous() and (y is None or y.is_contiguous())
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib().flair_axpby_f32(ptr(x), ptr(y), ctypes.c_float(a), ctypes.c_float(b), ctypes.c_float(lo),
+                                ctypes.c_float(hi), ctypes.c_long(x.numel()), ptr(out), stream()),
+          "flair_axpby_f32")
+    return out
+
+
+def learned_range_variance(model_out, C, min_log, max_log):
+    N, C2, H, W = model_out.shape
+    var = torch.empty((N, C, H, W), dtype=torch.float32, device=model_out.device)
+    logvar = torch.empty_like(var)
+    check(lib().flair_learned_range_variance(ptr(model_out), N, C, H, W, ctypes.c_float(min_log),
+                                             ctypes.c_float(max_log), ptr(var), ptr(logvar), stream()),
+          "flair_learned_range_variance")
+    return var, logvar

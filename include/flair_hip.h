@@ -155,8 +155,15 @@ int flair_predict_xstart(const float* x, const float* model_out, int N, int C, i
 int flair_sampler_update(const flair_sampler_coefs* c, const float* x, float* x0,
                          const float* restored, const float* aux, const float* z,
                          const float* prev_recon, long n, float* x_prev, hipStream_t stream);
-int flair_axpby_f32(const float* x, const float* y, float a, float b, long n, float* out,
-                    hipStream_t stream);
+/* out = clamp(a*x + b*y, lo, hi) on flat f32 tensors (y may be NULL): q_sample,
+ * posterior mean, eps-from-x0 (gaussian_diffusion.py:206-248,361-365). */
+int flair_axpby_f32(const float* x, const float* y, float a, float b, float lo, float hi, long n,
+                    float* out, hipStream_t stream);
+/* LEARNED_RANGE model variance (gaussian_diffusion.py:285-292) from channels [C,2C) of the
+ * (N,2C,H,W) model output. */
+int flair_learned_range_variance(const float* model_out, int N, int C, int H, int W, float min_log,
+                                 float max_log, float* variance, float* log_variance,
+                                 hipStream_t stream);
 /* y[p][c] = (clamp(x[p][c]*a + b, lo, hi) - sub[c]) * mul[c] on f32 pixels (SPyNet input
  * normalisation: unet_new.py:1300 and mmedit SPyNet's mean/std). */
 int flair_affine_channels_f32(const float* x, int x_ld, int C, long P, float a, float b, float lo,
@@ -211,7 +218,8 @@ int flair_flow_warp(const void* x, int dtype, int x_ld, const float* flow, int f
 /* out = f1 + warp(f2, f1) on flow fields (unet_new.py:716-718). */
 int flair_flow_compose(const float* f1, const float* f2, int F, int H, int W, float* out,
                        hipStream_t stream);
-/* mode 0/1: bilinear (align_corners False/True), 2: bicubic (A=-0.75), 3: 2x2 avg-pool;
+/* mode 0/1: bilinear (align_corners False/True), 2: bicubic (A=-0.75), 3: 2x2 avg-pool,
+ * 4: nearest;
  * channel 0 / 1 of the result are multiplied by scale_c0 / scale_c1 (flow rescaling). */
 int flair_resize_nhwc(const void* x, int dtype, int x_ld, int F, int Hi, int Wi, int C, int mode,
                       int Ho, int Wo, void* y, int y_ld, float scale_c0, float scale_c1,
