@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Headline benchmark: restored frames/s of FLAIR's sampling hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): gaussian-demo, one clip of 16 frames at 256x256 per
+GPU, 250-step generalised-DDIM chain (space_timesteps(1000,"250"), rho=0.25), bf16 UNet
+(unet_new.UNetModel, 405.6 M parameters, random init), Gaussian-blur x4 data-consistency
+operator on the GPU, identity aux prior with aligned=True.  A "step" is one denoising step
+of the clip = one UNet forward + restore_fn + fused sampler update.  W warm-up steps, then
+exactly K steps are timed between barrier + synchronize; frames/s for the whole 250-step
+job is  n_gpus * frames / (250 * mean step time)  (with the default K = 248 the timed region
+is the whole chain but the warm-up steps).  Inputs are resident in HBM before timing.
+
+The JSON line also carries
+  roofline     -- the dominant kernel (implicit-GEMM conv on MFMA): algorithmic FLOPs of its
+                  launches / their summed HIP-event durations in one extra instrumented step;
+  cpu_baseline -- the CPU oracle (oracle/, torch fp32) on this host's cores on a bounded
+                  sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+TOTAL_STEPS = 250
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense, MI355X_MICROARCH.md
+CONV_VARIANTS = {0: "conv_igemm<128co x 128px>", 1: "conv_igemm<64co x 128px>", 2: "conv_igemm<64co x 64px>"}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=TOTAL_STEPS - 2)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--task", default="gaussian", choices=["gaussian", "jpeg"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(size, frames_sample=2):
+    """Oracle (port) timed on the host: one UNet forward = one denoising step's dominant cost,
+    on `frames_sample` frames of the same resolution and network; scaled to frames/s of the
+    250-step job."""
+    from oracle.unet import UNetModel as Oracle
+    from flair_amd.workload import blur_config, randomize_zero_modules
+    n_threads = torch.get_num_threads()
+    torch.manual_seed(0)
+    cfg = blur_config(size, use_fp16=False)
+    t0 = time.time()
+    o = Oracle(**cfg).eval()
+    randomize_zero_modules(o)
+    T = frames_sample
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(T, 3, size, size, generator=g)
+    lr = torch.rand(1, T, 3, size, size, generator=g) * 2 - 1
+    t = torch.full((T,), 500, dtype=torch.long)
+    build = time.time() - t0
+    t0 = time.time()
+    with torch.no_grad():
+        o(x, t, low_res_input=lr, num_frames=T, vsrpp_weights=1.0)
+    dt = time.time() - t0
+    return {"value": T / (TOTAL_STEPS * dt), "unit": "frames/s", "cores": n_threads, "kind": "port",
+            "sample": f"oracle/unet.py fp32, 1 denoising step (UNet forward incl. SPyNet) of {T} frames at "
+                      f"{size}x{size}: {dt:.1f} s (model build {build:.0f} s); scaled by {TOTAL_STEPS} steps"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from flair_amd import ops, parallel
+    from flair_amd import workload as wl
+    from flair_amd.guided_diffusion import pseudoSR as psr
+    from flair_amd.guided_diffusion.jpeg import jpeg_decode, jpeg_encode
+    from flair_amd.guided_diffusion.unet_new import UNetModel
+
+    S, T = a.size, a.frames
+    hp = wl.TASKS[a.task]
+    torch.manual_seed(0)
+    model = UNetModel(**wl.blur_config(S, use_fp16=(a.dtype == "bf16")))
+    if rank == 0:
+        wl.randomize_zero_modules(model)
+    model = model.to(dev).eval()
+    t_bcast = parallel.broadcast_weights(model, src=0) if world > 1 else 0.0
+    if a.dtype == "bf16":
+        model.convert_to_fp16()
+    diffusion = wl.diffusion_for(TOTAL_STEPS)
+    conf = psr.Get_pseudoSR_Conf(4)
+    A_func = psr.pseudoSR(conf, upscale_kernel=wl.synthetic_blur_kernel(), kernel_indx=10).WrapArchitecture_PyTorch().to(dev)
+
+    clip_id = rank                                     # weak scaling: one clip per GPU
+    degraded, init, rnn = (v.to(dev) for v in wl.clip_inputs(a.task, clip_id, T, S))
+    lr_flat = degraded[0].contiguous()
+    qf = hp["jpeg_qf"]
+
+    def restore_fn(x0):
+        return A_func.A_pinv(lr_flat, x0,
+                             jpeg_encode=(lambda im: jpeg_encode(im, qf)) if qf != -1 else None,
+                             jpeg_decode=(lambda im: jpeg_decode(im, qf)) if qf != -1 else None)
+
+    g = torch.Generator(device=dev).manual_seed(4321 + clip_id)
+    tt = torch.full((T,), diffusion.num_timesteps - 1, device=dev, dtype=torch.long)
+    x_T = diffusion.q_sample(init[0].contiguous(), tt, noise=torch.randn(T, 3, S, S, device=dev, generator=g))
+    kwargs = dict(low_res_input=init, num_frames=T, enable_cross_frames=True, vsrpp_weights=1.0, rnn_input=rnn)
+
+    W = max(0, a.warmup)
+    K = max(1, min(a.steps, TOTAL_STEPS - W - 1))      # keep one step for the instrumented pass
+    gen = diffusion.p_sample_loop_progressive(
+        model, x_T.shape, noise=x_T, clip_denoised=True, model_kwargs=kwargs, device=dev,
+        restore_fn=restore_fn, aux_model=wl.identity_aux, w=hp["w"], tau=5, aligned=True, rho=hp["rho"],
+        noise_level=hp["noise_level"], zeta=hp["zeta"])
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(W):
+        next(gen)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        out = next(gen)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    finite = bool(torch.isfinite(out["sample"]).all().item())
+
+    # ---- roofline leg: one more step with every conv launch bracketed by HIP events ------
+    ops.CONV_PROFILE = []
+    next(gen)
+    torch.cuda.synchronize()
+    prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
+    per = {}
+    for variant, dt_name, flops, e0, e1 in prof:
+        d = per.setdefault((variant, dt_name), [0, 0.0, 0.0])
+        d[0] += 1
+        d[1] += flops
+        d[2] += e0.elapsed_time(e1) * 1e-3
+    key = max(per, key=lambda k: per[k][2])
+    calls, flops, secs = per[key]
+    achieved = flops / secs / 1e12
+    peak = MFMA_PEAK_TFLOPS["bf16" if "bfloat16" in key[1] else "f32"]
+    all_flops = sum(v[1] for v in per.values())
+    all_secs = sum(v[2] for v in per.values())
+
+    ms_per_step = 1e3 * elapsed / K
+    value = world * T / (TOTAL_STEPS * elapsed / K)
+    line = {
+        "metric": "restored frames/sec at 256x256, 16-frame clip, 250-step DDIM",
+        "value": value, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": a.dtype, "data": "synthetic",
+        "config": {"workload": f"{a.task}-demo, {world} clip(s) x {T} frames x {S}x{S}, "
+                               f"{TOTAL_STEPS}-step generalised DDIM (rho={hp['rho']}), unet_new.UNetModel "
+                               f"405.6M params random init, blur x4 restore_fn on GPU, one clip per GPU",
+                   "steps_per_clip": TOTAL_STEPS, "value_definition": "n_gpus*frames/(250*mean timed step)",
+                   "finite_output": finite, "weight_broadcast_s": t_bcast},
+        "roofline": {"bound": "mfma", "kernel": CONV_VARIANTS.get(key[0], str(key[0])) + " " + key[1],
+                     "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                     "traffic": None, "launches": calls, "avg_launch_us": 1e6 * secs / calls,
+                     "all_conv_achieved": all_flops / all_secs / 1e12,
+                     "all_conv_share_of_step": all_secs / (ms_per_step * 1e-3)},
+    }
+    if rank == 0:
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(S)
+            except Exception as exc:  # the baseline must never hide the measurement
+                line["cpu_baseline"] = {"value": None, "error": repr(exc)}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

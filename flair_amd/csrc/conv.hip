@@ -293,17 +293,31 @@ int launch(const ConvArgs& a0, hipStream_t s) {
     return FLAIR_OK;
 }
 
+// Tile choice: keep >= ~2 workgroups per CU when the problem allows it.
+// 0: 128 couts x 128 pixels, 1: 64 x 128, 2: 64 x 64.
+int choose_variant(long P, int Cout) {
+    const long tiles128 = (long)cdiv(P, 128) * cdiv(Cout, 128);
+    if (Cout > 64 && tiles128 >= 512) return 0;
+    const long tiles64x128 = (long)cdiv(P, 128) * cdiv(Cout, 64);
+    if (tiles64x128 >= 512) return 1;
+    return 2;
+}
+
 template <typename E>
 int dispatch(const ConvArgs& a, hipStream_t s) {
-    // Tile choice: keep >= ~2 workgroups per CU when the problem allows it.
-    const long tiles128 = (long)cdiv(a.P, 128) * cdiv(a.Cout, 128);
-    if (a.Cout > 64 && tiles128 >= 512) return launch<E, 128, 128, 2, 2>(a, s);
-    const long tiles64x128 = (long)cdiv(a.P, 128) * cdiv(a.Cout, 64);
-    if (tiles64x128 >= 512) return launch<E, 64, 128, 1, 4>(a, s);
-    return launch<E, 64, 64, 2, 2>(a, s);
+    switch (choose_variant(a.P, a.Cout)) {
+        case 0: return launch<E, 128, 128, 2, 2>(a, s);
+        case 1: return launch<E, 64, 128, 1, 4>(a, s);
+        default: return launch<E, 64, 64, 2, 2>(a, s);
+    }
 }
 
 }  // namespace
+
+extern "C" int flair_conv_variant(const flair_conv_params* p) {
+    if (!p) return -1;
+    return choose_variant((long)p->T * p->H * p->W, p->Cout);
+}
 
 extern "C" int flair_conv_nhwc(const flair_conv_params* p, const void* const* x, const void* w,
                                const float* bias, const void* res0, const void* res1, void* y,

@@ -119,9 +119,22 @@ def conv(xs, weight, bias, cout, kernel, *, out=None, act=ACT_NONE, res0=None, r
     p.act = act
     p.out_scale = out_scale
     assert weight.dtype == x0.dtype and weight.is_contiguous()
+    prof = CONV_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(lib().flair_conv_nhwc(ctypes.byref(p), arr, ptr(weight), ptr(_f32(bias)), ptr(res0),
                                 ptr(res1), ptr(out), stream()), "flair_conv_nhwc")
+    if prof is not None:
+        e1.record()
+        cin = sum(x.shape[3] for x in xs)
+        flops = 2.0 * T * H * W * cout * cin * kernel[0] * kernel[1] * kernel[2]
+        prof.append((lib().flair_conv_variant(ctypes.byref(p)), str(x0.dtype), flops, e0, e1))
     return out
+
+
+# bench.py sets this to a list to time every conv launch with HIP events (roofline leg)
+CONV_PROFILE = None
 
 
 def pack_conv_weight(w, seg_channels, dtype, cout_pad=None):
@@ -414,3 +427,53 @@ def learned_range_variance(model_out, C, min_log, max_log):
                                              ctypes.c_float(max_log), ptr(var), ptr(logvar), stream()),
           "flair_learned_range_variance")
     return var, logvar
+
+
+# ------------------------------------------------------------------- degradation ops
+def depthwise_filter(x, filt, *, pad, out_stride=1, out_offset=0, stuff=1, stuff_offset=0, out_hw=None):
+    """x: (N,C,H,W) f32; filt: (kh,kw) f32 device tensor shared by all planes."""
+    N, C, H, W = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous() and filt.dtype == torch.float32 and filt.is_contiguous()
+    Ho, Wo = out_hw
+    out = torch.empty((N, C, Ho, Wo), dtype=torch.float32, device=x.device)
+    check(lib().flair_depthwise_filter(ptr(x), N * C, H, W, ptr(filt), filt.shape[0], filt.shape[1], pad,
+                                       out_stride, out_offset, stuff, stuff_offset, Ho, Wo, ptr(out), stream()),
+          "flair_depthwise_filter")
+    return out
+
+
+def jpeg_roundtrip(x, q_luma, q_chroma, dct8):
+    """x: (N,3,S,S) f32 in [-1,1]; tables: python sequences / numpy arrays of 64 floats (host)."""
+    N, C, S, _ = x.shape
+    assert C == 3 and x.dtype == torch.float32 and x.is_contiguous()
+    arr = ctypes.c_float * 64
+    ws = torch.empty_like(x)
+    out = torch.empty_like(x)
+    check(lib().flair_jpeg_roundtrip(ptr(x), N, S, arr(*[float(v) for v in q_luma]),
+                                     arr(*[float(v) for v in q_chroma]), arr(*[float(v) for v in dct8]),
+                                     ptr(ws), ptr(out), stream()), "flair_jpeg_roundtrip")
+    return out
+
+
+def matmul(a, b):
+    """Batched f32 matmul; a: (B,M,K) or (M,K) shared; b: (B,K,N) or (K,N) shared."""
+    assert a.dtype == torch.float32 and b.dtype == torch.float32 and a.is_contiguous() and b.is_contiguous()
+    batch = a.shape[0] if a.dim() == 3 else (b.shape[0] if b.dim() == 3 else 1)
+    M, K = a.shape[-2:]
+    N = b.shape[-1]
+    assert b.shape[-2] == K
+    out = torch.empty((batch, M, N), dtype=torch.float32, device=a.device)
+    check(lib().flair_matmul_f32(ptr(a), ctypes.c_long(M * K if a.dim() == 3 else 0), ptr(b),
+                                 ctypes.c_long(K * N if b.dim() == 3 else 0), ptr(out), batch, M, N, K, stream()),
+          "flair_matmul_f32")
+    return out
+
+
+def gather_mac(x, outer, lin, inner, fov, w):
+    """Resizer step: x viewed [outer][lin][inner] f32; fov int32 (taps,Lout); w f32 (taps,Lout)."""
+    taps, lout = fov.shape
+    assert x.dtype == torch.float32 and x.is_contiguous() and fov.dtype == torch.int32 and w.dtype == torch.float32
+    out = torch.empty((outer, lout, inner), dtype=torch.float32, device=x.device)
+    check(lib().flair_gather_mac_f32(ptr(x), ctypes.c_long(outer), lin, ctypes.c_long(inner), ptr(fov.contiguous()),
+                                     ptr(w.contiguous()), taps, lout, ptr(out), stream()), "flair_gather_mac_f32")
+    return out

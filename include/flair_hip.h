@@ -84,6 +84,9 @@ typedef struct {
 int flair_conv_nhwc(const flair_conv_params* p, const void* const* x, const void* w,
                     const float* bias, const void* res0, const void* res1, void* y,
                     hipStream_t stream);
+/* Which tile variant flair_conv_nhwc launches for these parameters (profiling aid):
+ * 0 = 128 couts x 128 pixels, 1 = 64 x 128, 2 = 64 x 64 per workgroup. */
+int flair_conv_variant(const flair_conv_params* p);
 
 
 /* ------------------------------------------------------- GroupNorm + SiLU (+ FiLM)
@@ -242,6 +245,33 @@ typedef struct {
 int flair_dcn_align(const flair_dcn_params* p, const void* x0, const void* x1, const void* raw,
                     const float* flow1, const float* flow2, const void* w, const float* bias,
                     void* y, hipStream_t stream);
+
+/* ------------------------------------------------- degradation operators (restore_fn)
+ * Images here are the sampler's (N,C,H,W) f32 tensors.
+ *
+ * flair_depthwise_filter: pseudoSR's Filter_Layer (pseudoSR.py:15-44,174-246): every plane is
+ * cross-correlated with one kh x kw filter after replication padding:
+ *   out[i][j] = sum_{u,v} K[u][v] * IN(i*out_stride + out_offset + u - pad, j*... + v - pad)
+ * where IN clamps to the virtual image of size (Hin*stuff, Win*stuff) whose samples are zero
+ * except at coordinates == stuff_offset (mod stuff) (zero-stuffing up-sampler).
+ *   Down  : pad 4, out_stride 4, out_offset pre_stride;  InvHtH: pad 19;  Up: stuff 4. */
+int flair_depthwise_filter(const float* x, int planes, int Hin, int Win, const float* filt, int kh,
+                           int kw, int pad, int out_stride, int out_offset, int stuff,
+                           int stuff_offset, int Hout, int Wout, float* y, hipStream_t stream);
+/* jpeg_decode(jpeg_encode(x, qf), qf) of jpeg.py:72-167 on (N,3,S,S) images in [-1,1].
+ * q_luma, q_chroma, dct8 are HOST arrays of 64 floats (quantisation tables of
+ * general_quant_matrix, jpeg.py:35-65, and the 8x8 orthonormal DCT-II matrix); workspace:
+ * N*3*S*S device floats. */
+int flair_jpeg_roundtrip(const float* x, int N, int S, const float* q_luma, const float* q_chroma,
+                         const float* dct8, float* workspace, float* y, hipStream_t stream);
+/* C[b] = A[b] (MxK) * B[b] (KxN), row-major f32; a stride of 0 shares the matrix across the
+ * batch.  SRConv's separable U/V products (restore_util.py:102-227). */
+int flair_matmul_f32(const float* A, long a_batch_stride, const float* B, long b_batch_stride,
+                     float* C, int batch, int M, int N, int K, hipStream_t stream);
+/* Resizer (resizer.py:54-73) along one axis of a tensor viewed [outer][Lin][inner]:
+ * y[o][i][n] = sum_k w[k][i] * x[o][fov[k][i]][n]; fov int32 [taps][Lout], w f32 [taps][Lout]. */
+int flair_gather_mac_f32(const float* x, long outer, int Lin, long inner, const int* fov,
+                         const float* w, int taps, int Lout, float* y, hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,119 @@
+"""Sampler + degradation-operator parity on the GPU (HIP kernels through the C ABI vs oracle)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def toy_model(x, t, **kw):
+    """Cheap deterministic stand-in network: (N,3,H,W) -> (N,6,H,W); identical maths on CPU/GPU
+    up to f32 rounding of tanh."""
+    tt = t.float().view(-1, 1, 1, 1) / 1000.0
+    eps = torch.tanh(x * 0.7 + tt) * 0.9 + 0.1 * x.roll(1, dims=3)
+    v = torch.sin(x * 1.3 - tt)
+    return torch.cat([eps, v], dim=1)
+
+
+@pytest.mark.parametrize("case", [
+    dict(steps="10", restore=True, prev=False, t_start=-1, zeta=1.0, noise_level=2.55, w=0.75, rho=0.25, tau=2),
+    dict(steps="10", restore=False, prev=True, t_start=6, zeta=-1, noise_level=None, w=0.5, rho=0.5, tau=0),
+    dict(steps="25", restore=True, prev=True, t_start=-1, zeta=1.0, noise_level=12.75, w=0.5, rho=0.0, tau=5),
+])
+def test_sampler_trajectory_vs_oracle(dev, case):
+    from flair_amd import workload as wl
+    from flair_amd.guided_diffusion import pseudoSR as psr
+    from oracle import degrade as odeg
+    from oracle import diffusion as odiff
+    T, S = 4, 32
+    g = torch.Generator().manual_seed(17)
+    x_T = torch.randn(T, 3, S, S, generator=g)
+    lr = torch.rand(T, 3, S // 4, S // 4, generator=g) * 2 - 1
+    prev = torch.rand(1, 2, 3, S, S, generator=g) * 2 - 1 if case["prev"] else None
+    kern = wl.synthetic_blur_kernel()
+    n = int(case["steps"])
+    tape = [torch.randn(T, 3, S, S, generator=g) for _ in range(n)]
+    tab = odiff.Spaced(odiff.spaced_steps(1000, case["steps"]), odiff.named_betas("face_blur", 1000))
+    oblur = odeg.BlurOperator(kern, 4)
+    aux = lambda x0, t, xt: (0.8 * x0 + 0.1 * xt)            # noqa: E731
+    ref_trace = []
+    ref = odiff.sample_loop(tab, toy_model, x_T, model_kwargs=dict(num_frames=T),
+                            restore_fn=(lambda x0: oblur.a_pinv(lr, x0)) if case["restore"] else None,
+                            aux_model=aux, w=case["w"], tau=case["tau"], rho=case["rho"],
+                            noise_level=case["noise_level"], zeta=case["zeta"], prev_recon=prev,
+                            t_start=case["t_start"], step_noise=tape, trace=ref_trace)
+    diffusion = wl.diffusion_for(n)
+    A = psr.pseudoSR(psr.Get_pseudoSR_Conf(4), upscale_kernel=kern, kernel_indx=10).WrapArchitecture_PyTorch().to(dev)
+    lr_d = lr.to(dev)
+
+    class M:                                    # gives the loop a .parameters() like an nn.Module
+        def parameters(self):
+            return iter([x_T.to(dev)])
+
+        def __call__(self, x, t, **kw):
+            return toy_model(x, t, **kw)
+    got_trace = []
+    got = diffusion.p_sample_loop(
+        M(), x_T.shape, noise=x_T.to(dev), model_kwargs=dict(num_frames=T), device=dev,
+        restore_fn=(lambda x0: A.A_pinv(lr_d, x0)) if case["restore"] else None, aux_model=aux,
+        post_fn=lambda o: got_trace.append((int(o["t"][0]), o["pred_xstart"].cpu(), o["sample"].cpu())),
+        w=case["w"], tau=case["tau"], aligned=True, rho=case["rho"], noise_level=case["noise_level"],
+        zeta=case["zeta"], prev_recon=prev.to(dev) if prev is not None else None, t_start=case["t_start"],
+        noise_fn=lambda it, like: tape[it].to(dev))
+    assert len(got_trace) == len(ref_trace)
+    for (ti, x0r, sr), (tg, x0g, sg) in zip(ref_trace, got_trace):
+        assert ti == tg
+        # tolerance: f32 elementwise chain, amplified by up to 1/sqrt_recipm1 at small t -> 2e-4 abs on [-1,1] data
+        assert (x0r - x0g).abs().max().item() <= 2e-4, (ti, (x0r - x0g).abs().max().item())
+        assert (sr - sg).abs().max().item() <= 5e-4 * max(1.0, sr.abs().max().item()), ti
+    assert (ref - got.cpu()).abs().max().item() <= 5e-4
+
+
+def test_schedules_match_oracle():
+    """ws / gammas ramps (host float64) -- exact."""
+    from flair_amd import workload as wl
+    from oracle import diffusion as odiff
+    for steps, w, tau, zeta, nl in [(50, 0.75, 5, 1.0, 2.55), (100, 0.5, 5, 1.0, 12.75), (250, 0.85, 0, -1, 0.0)]:
+        d = wl.diffusion_for(steps)
+        tab = odiff.Spaced(odiff.spaced_steps(1000, str(steps)), odiff.named_betas("face_blur", 1000))
+        ws, gm = d.schedules(steps - 1, tau, w, zeta, nl)
+        assert np.array_equal(ws, odiff.aux_weights(tab, steps - 1, tau, w))
+        assert np.array_equal(gm, odiff.consistency_gammas(tab, zeta, nl))
+        assert d.timestep_map == tab.timestep_map
+
+
+@pytest.mark.parametrize("size", [32, 64])
+def test_blur_operator_vs_oracle(dev, size):
+    from flair_amd import workload as wl
+    from flair_amd.guided_diffusion import pseudoSR as psr
+    from oracle import degrade as odeg
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(3, 3, size, size, generator=g) * 2 - 1
+    lr = torch.rand(3, 3, size // 4, size // 4, generator=g) * 2 - 1
+    kern = wl.synthetic_blur_kernel(sigma=1.8)
+    o = odeg.BlurOperator(kern, 4)
+    A = psr.pseudoSR(psr.Get_pseudoSR_Conf(4), upscale_kernel=kern, kernel_indx=10).WrapArchitecture_PyTorch().to(dev)
+    for name, got, ref in [("down", A.DownscaleOP(x.to(dev)), o.down(x)),
+                           ("inv", A.Conv_LR_with_Inv_hTh_OP(lr.to(dev)), o.inv(lr)),
+                           ("up", A.Upscale_OP(lr.to(dev)), o.up(lr)),
+                           ("a_pinv", A.A_pinv(lr.to(dev), x.to(dev)), o.a_pinv(lr, x)),
+                           ("a_pinv_lr", A.A_pinv(lr.to(dev)), o.a_pinv(lr))]:
+        err = (got.cpu() - ref).abs().max().item()
+        assert err <= 2e-5 * max(1.0, ref.abs().max().item()), (name, err)
+
+
+@pytest.mark.parametrize("qf", [10, 60, 90])
+def test_jpeg_roundtrip_vs_oracle(dev, qf):
+    from flair_amd.guided_diffusion.jpeg import jpeg_decode, jpeg_encode
+    from oracle import degrade as odeg
+    g = torch.Generator().manual_seed(qf)
+    base = torch.rand(2, 3, 8, 8, generator=g) * 2 - 1
+    x = (torch.nn.functional.interpolate(base, (64, 64), mode="bilinear") + 0.1 * torch.randn(2, 3, 64, 64, generator=g)).clamp(-1, 1)
+    ref = odeg.jpeg_decode(odeg.jpeg_encode(x, qf), qf)
+    got = jpeg_decode(jpeg_encode(x.to(dev), qf), qf).cpu()
+    diff = (got - ref).abs()
+    # quantisation rounds at .5 boundaries: an f32 last-bit difference in a DCT coefficient can
+    # flip one level in one 8x8 block (rare).  Bit-level agreement elsewhere: <=1e-4; allow
+    # <=0.5% of pixels to sit in a flipped block.
+    frac_bad = (diff > 1e-4).float().mean().item()
+    assert frac_bad <= 5e-3, (frac_bad, diff.max().item())

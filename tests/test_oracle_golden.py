@@ -1,0 +1,189 @@
+"""CPU: pin the oracle (and the product's host-side logic) to the golden vectors generated from
+the reference's own Python (tests/golden/make_golden.py).  No GPU, no /root/reference needed."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden.weights import name_seeded_weights
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return dict(np.load(os.path.join(G, name + ".npz")))
+
+
+SMALL = dict(image_size=32, in_channels=6, model_channels=128, out_channels=6, num_res_blocks=1,
+             attention_resolutions=(2, 4), rnn_resolutions=(1, 2), channel_mult=(0.5, 1, 4), use_fp16=False,
+             num_head_channels=64, resblock_updown=True, use_scale_shift_norm=True, temporal_block=True,
+             use_checkpoint=False)
+
+TABLES = ("betas", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "sqrt_alphas_cumprod_prev",
+          "sqrt_one_minus_alphas_cumprod_prev", "posterior_log_variance_clipped", "posterior_mean_coef1",
+          "posterior_mean_coef2")
+
+
+@pytest.mark.parametrize("sched,base,count", [("face_blur", 1000, "50"), ("face_blur", 1000, "100"),
+                                              ("face_blur", 1000, "250"), ("face_bicubic", 2000, "100")])
+def test_tables_and_maps(sched, base, count):
+    """Bit-exact float64 tables + integer timestep maps, for the oracle AND the product's host code."""
+    from oracle import diffusion as od
+    from flair_amd.guided_diffusion import gaussian_diffusion as gd
+    from flair_amd.guided_diffusion import respace as rs
+    g = load("g1_tables")
+    key = f"{sched}_{count}"
+    tab = od.Spaced(od.spaced_steps(base, count), od.named_betas(sched, base))
+    d = rs.SpacedDiffusion(use_timesteps=rs.space_timesteps(base, count, "uniform"),
+                           betas=gd.get_named_beta_schedule(sched, base), model_mean_type=gd.ModelMeanType.EPSILON,
+                           model_var_type=gd.ModelVarType.LEARNED_RANGE, loss_type=gd.LossType.MSE)
+    for obj in (tab, d):
+        assert np.array_equal(np.array(obj.timestep_map), g[key + "_map"])
+        for t in TABLES:
+            assert np.array_equal(getattr(obj, t), g[f"{key}_{t}"]), (type(obj).__name__, t)
+
+
+def test_space_timesteps_variants():
+    from oracle import diffusion as od
+    from flair_amd.guided_diffusion import respace as rs
+    g = load("g1_tables")
+    for fn in (od.spaced_steps, rs.space_timesteps):
+        assert np.array_equal(np.array(sorted(fn(1000, "ddim25"))), g["ddim25"])
+        assert np.array_equal(np.array(fn(1000, 20, "quad")), g["quad20"])
+        assert np.array_equal(np.array(sorted(fn(300, "10,15,20"))), g["sections"])
+        with pytest.raises(ValueError):
+            fn(10, "11")
+        with pytest.raises(ValueError):
+            fn(1000, "ddim999")
+
+
+def _toy(x, t, **kw):
+    tt = t.float().view(-1, 1, 1, 1) / 1000.0
+    eps = torch.tanh(x * 0.7 + tt) * 0.9 + 0.1 * x.roll(1, dims=3)
+    return torch.cat([eps, torch.sin(x * 1.3 - tt)], dim=1)
+
+
+CASES = {
+    "lr_restore": dict(learned=True, steps="10", restore=True, prev=False, t_start=-1, zeta=1.0, noise_level=2.55,
+                       w=0.75, rho=0.25, tau=2),
+    "fs_prev_tstart": dict(learned=False, steps="10", restore=False, prev=True, t_start=6, zeta=-1,
+                           noise_level=None, w=0.5, rho=0.5, tau=0),
+    "lr_all": dict(learned=True, steps="12", restore=True, prev=True, t_start=-1, zeta=1.0, noise_level=12.75,
+                   w=0.5, rho=0.0, tau=5),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_sampler_trajectory(name):
+    """Oracle sampler vs the reference's p_sample_loop on the same injected noise: every step."""
+    from oracle import diffusion as od
+    g = load("g3_sampler")
+    c = CASES[name]
+    x_T = torch.from_numpy(g["x_T"])
+    prev = torch.from_numpy(g["prev"]) if c["prev"] else None
+    tape = list(torch.from_numpy(g["tape"]))
+    tab = od.Spaced(od.spaced_steps(1000, c["steps"]), od.named_betas("face_blur", 1000))
+    trace = []
+    od.sample_loop(tab, _toy, x_T, model_kwargs=dict(num_frames=4), learned_range=c["learned"],
+                   restore_fn=(lambda x0: 0.3 * x0 - 0.1 * x0.flip(2)) if c["restore"] else None,
+                   aux_model=lambda x0, t, xt: 0.8 * x0 + 0.1 * xt, w=c["w"], tau=c["tau"], rho=c["rho"],
+                   noise_level=c["noise_level"], zeta=c["zeta"], prev_recon=prev, t_start=c["t_start"],
+                   step_noise=tape, trace=trace)
+    assert len(trace) == g[name + "_samples"].shape[0]
+    for k, (i, x0, s) in enumerate(trace):
+        assert np.abs(x0.numpy() - g[name + "_x0"][k]).max() <= 2e-6, (name, k)
+        assert np.abs(s.numpy() - g[name + "_samples"][k]).max() <= 5e-6, (name, k)
+    # the recorded ramps (w_t, gamma_t) of the reference, as f32
+    start = trace[0][0]
+    ws = od.aux_weights(tab, start, c["tau"], c["w"])
+    gm = od.consistency_gammas(tab, c["zeta"], c["noise_level"])
+    rec = g[name + "_w_gamma"]
+    idx = [i for i, _, _ in trace]
+    assert np.allclose(np.float32(ws[idx]), rec[:, 0], rtol=0, atol=1e-7)
+    assert np.allclose(np.float32(gm[idx]), rec[:, 1], rtol=0, atol=1e-7)
+
+
+def test_unet_small_and_flows():
+    """Oracle UNet (name-seeded weights) vs the reference's forward: final output, 8 intermediate
+    stages (stored as fp16) and the SPyNet flows."""
+    from oracle.unet import UNetModel, timestep_embedding
+    g = load("g5_unet_small")
+    torch.manual_seed(0)
+    o = name_seeded_weights(UNetModel(**SMALL)).eval()
+    x, lr, t = torch.from_numpy(g["x"]), torch.from_numpy(g["lr"]), torch.from_numpy(g["t"])
+    stages = {}
+
+    def hook(nm):
+        def f(mod, inp, out):
+            stages[nm] = out[0]
+        return f
+    for i, b in enumerate(o.input_blocks):
+        b.register_forward_hook(hook(f"stage_input_blocks_{i}"))
+    o.middle_block.register_forward_hook(hook("stage_middle_block"))
+    for i, b in enumerate(o.output_blocks):
+        b.register_forward_hook(hook(f"stage_output_blocks_{i}"))
+    with torch.no_grad():
+        y = o(x, t, low_res_input=lr, num_frames=4, vsrpp_weights=1.0)
+        ff, fb = o.compute_flow(lr)
+    assert np.abs(y.numpy() - g["y"]).max() <= 1e-5 * np.abs(g["y"]).max()
+    assert np.abs(ff.numpy() - g["flows_forward"]).max() <= 1e-5
+    assert np.abs(fb.numpy() - g["flows_backward"]).max() <= 1e-5
+    for k in g:
+        if k.startswith("stage_"):
+            ref = g[k].astype(np.float32)
+            assert np.abs(stages[k].numpy() - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-3, k
+    e = load("g4_timestep_embedding")
+    assert np.abs(timestep_embedding(torch.from_numpy(e["t"]).float(), 128).numpy() - e["emb"]).max() <= 1e-6
+
+
+def test_blur_filters_and_operator():
+    from oracle import degrade as od
+    from flair_amd.guided_diffusion import pseudoSR as psr
+    g = load("g6_degrade")
+    K = g["kernel_0_3"]
+    ds, inv, pre, post = od.blur_filters(K, 4)
+    assert np.array_equal(ds, g["ds_kernel"]) and np.array_equal(inv, g["inv_hTh"])
+    p = psr.pseudoSR(psr.Get_pseudoSR_Conf(4), upscale_kernel=K, kernel_indx=10)       # product host code
+    assert np.array_equal(p.ds_kernel, g["ds_kernel"]) and np.array_equal(p.inv_hTh, g["inv_hTh"])
+    op = od.BlurOperator(K, 4)
+    img, low = torch.from_numpy(g["img"]), torch.from_numpy(g["low"])
+    assert np.abs(op.a_pinv(low, img).numpy() - g["a_pinv"]).max() <= 2e-5
+    assert np.abs(op.a_pinv(low).numpy() - g["a_pinv_lr_only"]).max() <= 2e-5
+    codec = lambda v: od.jpeg_decode(od.jpeg_encode(v, 60), 60)    # noqa: E731
+    assert np.abs(op.a_pinv(low, img, codec=codec).numpy() - g["a_pinv_jpeg60"]).max() <= 5e-5
+
+
+@pytest.mark.parametrize("qf", [10, 60, 90])
+def test_jpeg(qf):
+    """Integer-valued quantised planes must match exactly; decoded RGB to f32 rounding."""
+    from oracle import degrade as od
+    from flair_amd.guided_diffusion.jpeg import general_quant_matrix
+    g = load("g6_degrade")
+    img = torch.from_numpy(g["img"])
+    luma, chroma = od.jpeg_encode(img, qf)
+    assert np.array_equal(luma.numpy(), g[f"jpeg{qf}_luma"])
+    assert np.array_equal(chroma.numpy(), g[f"jpeg{qf}_chroma"])
+    assert np.abs(od.jpeg_decode([luma, chroma], qf).numpy() - g[f"jpeg{qf}_dec"]).max() <= 1e-5
+    q1, q2 = od.quant_tables(qf)
+    p1, p2 = general_quant_matrix(qf)
+    assert np.array_equal(q1.numpy().reshape(-1), p1) and np.array_equal(q2.numpy().reshape(-1), p2)
+
+
+@pytest.mark.parametrize("f", [8, 16])
+def test_separable_sr(f):
+    from oracle import degrade as od
+    g = load("g6_degrade")
+    img = torch.from_numpy(g["img"])
+    sr = od.SeparableSR(torch.from_numpy(od.bicubic_taps(f)).float(), 3, 64, f)
+    y = sr.A(img.reshape(2, -1))
+    assert np.abs(y.numpy() - g[f"srconv{f}_A"]).max() <= 2e-5
+    assert np.abs(sr.A_pinv(torch.from_numpy(g[f"srconv{f}_A"])).numpy() - g[f"srconv{f}_pinv"]).max() <= 2e-4
+
+
+def test_resizer():
+    from oracle import degrade as od
+    g = load("g6_degrade")
+    img, low = torch.from_numpy(g["img"]), torch.from_numpy(g["low"])
+    assert np.abs(od.resize_apply(img, 1 / 8).numpy() - g["resizer_down8"]).max() <= 1e-5
+    assert np.abs(od.resize_apply(low, 8).numpy() - g["resizer_up8"]).max() <= 1e-5
