@@ -48,31 +48,33 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(size, frames_sample=2):
-    """Oracle (port) timed on the host: one UNet forward = one denoising step's dominant cost,
-    on `frames_sample` frames of the same resolution and network; scaled to frames/s of the
-    250-step job."""
+def cpu_baseline(size, frames_sample=2, sample_size=128):
+    """Oracle (port) timed on the host: one UNet forward (= one denoising step's dominant cost) of
+    `frames_sample` frames at `sample_size`^2 with the same network; conv work is linear in the
+    pixel count, so frames/s at `size`^2 = frames / (250 steps * dt * (size/sample_size)^2)."""
     from oracle.unet import UNetModel as Oracle
     from flair_amd.workload import blur_config, randomize_zero_modules
     n_threads = torch.get_num_threads()
     torch.manual_seed(0)
-    cfg = blur_config(size, use_fp16=False)
+    cfg = blur_config(sample_size, use_fp16=False)
     t0 = time.time()
     o = Oracle(**cfg).eval()
     randomize_zero_modules(o)
     T = frames_sample
     g = torch.Generator().manual_seed(5)
-    x = torch.randn(T, 3, size, size, generator=g)
-    lr = torch.rand(1, T, 3, size, size, generator=g) * 2 - 1
+    x = torch.randn(T, 3, sample_size, sample_size, generator=g)
+    lr = torch.rand(1, T, 3, sample_size, sample_size, generator=g) * 2 - 1
     t = torch.full((T,), 500, dtype=torch.long)
     build = time.time() - t0
     t0 = time.time()
     with torch.no_grad():
         o(x, t, low_res_input=lr, num_frames=T, vsrpp_weights=1.0)
     dt = time.time() - t0
-    return {"value": T / (TOTAL_STEPS * dt), "unit": "frames/s", "cores": n_threads, "kind": "port",
-            "sample": f"oracle/unet.py fp32, 1 denoising step (UNet forward incl. SPyNet) of {T} frames at "
-                      f"{size}x{size}: {dt:.1f} s (model build {build:.0f} s); scaled by {TOTAL_STEPS} steps"}
+    area = (size / sample_size) ** 2
+    return {"value": T / (TOTAL_STEPS * dt * area), "unit": "frames/s", "cores": n_threads, "kind": "port",
+            "sample": f"oracle/unet.py fp32 (torch CPU), 1 denoising step (UNet forward incl. SPyNet) of {T} "
+                      f"frames at {sample_size}x{sample_size}: {dt:.1f} s (model build {build:.0f} s); scaled to "
+                      f"{size}x{size} by pixel count (x{area:.0f}) and to the {TOTAL_STEPS}-step job"}
 
 
 def main():
