@@ -98,6 +98,18 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     }
 }
 
+// ---- buffer loads: out-of-range offsets return 0, which gives zero padding for free and keeps
+// the loads unconditional (a select or branch on a load result makes hipcc wait vmcnt(0) at once).
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+#define FLAIR_OOB 0x80000000u
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned byteOff) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byteOff, 0, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 // XCD-aware remap of a 1-D block id: blocks b and b+8 share an XCD (observed
 // round-robin dispatch), so give each XCD a contiguous chunk of the logical grid.
 // Bijective for any grid size (cdna_hip_programming.md section 5, "XCD swizzle").

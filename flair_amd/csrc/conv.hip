@@ -43,6 +43,8 @@ struct ConvArgs {
     float outScale;
     long P;  // T*H*W
     int nPixTiles, nCoTiles;
+    unsigned segBytes[4];  // addressable bytes of each input segment / of the weights
+    unsigned wBytes;
 };
 
 template <typename E> struct Mma;
@@ -76,6 +78,216 @@ template <> struct Mma<float> {
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {
     return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4);
+}
+
+// Epilogue for one register quad: 4 consecutive output channels of one pixel.
+template <typename E>
+__device__ __forceinline__ void store_quad(const ConvArgs& a, long p, int co, float v0, float v1, float v2, float v3) {
+    if (co >= a.Cout) return;  // Cout is a multiple of 4
+    float v[4] = {v0, v1, v2, v3};
+    if (a.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(a.bias + co);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], a.act);
+    const E* r0 = reinterpret_cast<const E*>(a.res0);
+    const E* r1 = reinterpret_cast<const E*>(a.res1);
+    if (r0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += ET<E>::ld(r0 + p * a.res0Ld + co + e);
+    }
+    if (r1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += ET<E>::ld(r1 + p * a.res1Ld + co + e);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= a.outScale;
+    E* dst = reinterpret_cast<E*>(a.y) + p * a.yLd + co;
+    if constexpr (sizeof(E) == 4) {
+        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+        uint2 pk;
+        pk.x = pack2bf(v[0], v[1]);
+        pk.y = pack2bf(v[2], v[3]);
+        *reinterpret_cast<uint2*>(dst) = pk;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// 3x3 (x KT) convolution with an LDS-staged HALO tile.
+//
+// The im2col kernel above re-reads every activation 9 (27) times from L2.  Here a workgroup
+// owns TH image rows x 32 columns of one frame and 64 output channels; per K chunk (64 bytes
+// of input channels, per temporal tap) it stages the (TH+2) x 34 pixel halo ONCE plus the 9
+// spatial taps of the weights, then runs all 9 taps x 2 MFMA k-steps out of LDS:
+// 18x fewer barriers per MFMA and ~7x less L2->LDS traffic.  One wavefront per image row:
+// lanes = 32 consecutive pixels (MFMA B operand, read at the tap-shifted halo address),
+// 64 couts = two A fragments.  Pixel pitch 80 B and weight row pitch 80 B make every
+// ds_read_b128 conflict-free (odd multiples of 16 B).  Loads of chunk k+1 are issued before
+// the MFMAs of chunk k (register staging), written after a barrier.
+template <typename E, int TH>
+__global__ __launch_bounds__(64 * TH) void conv3x3_halo_kernel(ConvArgs a) {
+    constexpr int BKE = Mma<E>::BKE;
+    constexpr int VEC = ET<E>::VEC;
+    constexpr int NT = 64 * TH;
+    constexpr int HW_ = 34;                        // halo width (32 + 2)
+    constexpr int PITCH = 80;                      // bytes per staged pixel / weight row
+    constexpr int HALO_PIECES = (TH + 2) * HW_ * 4;
+    constexpr int W_PIECES = 64 * 9 * 4;
+    constexpr int HI = (HALO_PIECES + NT - 1) / NT;
+    constexpr int WI = (W_PIECES + NT - 1) / NT;
+    constexpr int HALO_BYTES = (TH + 2) * HW_ * PITCH;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sh = smem;                // halo
+    char* sw = smem + HALO_BYTES;   // weights [64][9] rows of PITCH
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int coTile = bid % a.nCoTiles;
+    int rest = bid / a.nCoTiles;
+    const int tilesW = a.W / 32, tilesH = (a.H + TH - 1) / TH;
+    const int tw = rest % tilesW;
+    rest /= tilesW;
+    const int th = rest % tilesH;
+    const int t = rest / tilesH;
+    const int h0 = th * TH, w0 = tw * 32, co0 = coTile * 64;
+    const int taps = a.KT * 9;
+    const int pt = a.KT / 2;
+
+    uint4 hreg[HI], wreg[WI];
+    int dt = -pt, seg = 0, cb = 0, segOff = 0;
+    // skip temporal taps that fall outside the clip (block-uniform)
+    auto dt_valid = [&](int d) { return (unsigned)(t + d) < (unsigned)a.T; };
+    while (dt <= pt && !dt_valid(dt)) ++dt;
+
+    // per-thread piece coordinates, fixed over the K loop: pixel index inside the frame (or -1
+    // outside the image -> zero padding through the buffer range check) and weight row offset
+    constexpr unsigned ESZ = sizeof(E);
+    int hpix[HI];
+    unsigned hq[HI], woff[WI];
+#pragma unroll
+    for (int i = 0; i < HI; ++i) {
+        const int id = i * NT + tid;
+        const int pix = id >> 2;
+        const int r = pix / HW_, c = pix % HW_;
+        const int hh = h0 + r - 1, ww = w0 + c - 1;
+        const bool ok = id < HALO_PIECES && (unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W;
+        hpix[i] = ok ? hh * a.W + ww : -1;
+        hq[i] = (id & 3) * VEC * ESZ;
+    }
+    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.w, a.wBytes);
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+        const int id = i * NT + tid;
+        const int row = id >> 2;
+        const int co = row / 9, tap9 = row % 9;
+        const bool ok = id < W_PIECES && co0 + co < a.Cout;
+        woff[i] = ok ? (unsigned)(((co0 + co) * taps + tap9) * a.CinTot + (id & 3) * VEC) * ESZ : FLAIR_OOB;
+    }
+
+    auto issue = [&]() {
+        const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.x[seg], a.segBytes[seg]);
+        const unsigned ld = (unsigned)a.segLd[seg] * ESZ;
+        const int fbase = (t + dt) * a.H * a.W;
+        const unsigned cofs = (unsigned)(cb * BKE) * ESZ;
+#pragma unroll
+        for (int i = 0; i < HI; ++i) {
+            const unsigned off = hpix[i] >= 0 ? (unsigned)(fbase + hpix[i]) * ld + cofs + hq[i] : FLAIR_OOB;
+            hreg[i] = buf_load16(xr, off);
+        }
+        const unsigned kofs = (unsigned)((dt + pt) * 9 * a.CinTot + segOff + cb * BKE) * ESZ;
+#pragma unroll
+        for (int i = 0; i < WI; ++i) wreg[i] = buf_load16(wrs, woff[i] == FLAIR_OOB ? FLAIR_OOB : woff[i] + kofs);
+    };
+    auto advance = [&]() {   // the K loop is exhausted when dt > pt
+        ++cb;
+        if (cb * BKE >= a.segC[seg]) {
+            cb = 0;
+            segOff += a.segC[seg];
+            if (++seg >= a.nseg) {
+                seg = 0;
+                segOff = 0;
+                ++dt;
+                while (dt <= pt && !dt_valid(dt)) ++dt;
+            }
+        }
+    };
+    auto write_lds = [&]() {
+#pragma unroll
+        for (int i = 0; i < HI; ++i) {
+            const int id = i * NT + tid;
+            if (id < HALO_PIECES) *reinterpret_cast<uint4*>(sh + (id >> 2) * PITCH + (id & 3) * 16) = hreg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            const int id = i * NT + tid;
+            if (id < W_PIECES) *reinterpret_cast<uint4*>(sw + (id >> 2) * PITCH + (id & 3) * 16) = wreg[i];
+        }
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    issue();
+    advance();
+    write_lds();
+    __syncthreads();
+    bool more = dt <= pt;
+    while (true) {
+        if (more) issue();
+        // ---- 9 taps x 2 k-steps out of LDS
+        const char* hb = sh + ((wave * HW_) + lr) * PITCH;
+        const char* wb0 = sw + (lr * 9) * PITCH;
+        const char* wb1 = sw + ((lr + 32) * 9) * PITCH;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const char* hp = hb + (kh * HW_ + kw) * PITCH;
+                const int tap9 = kh * 3 + kw;
+                uint4 bf[2], a0[2], a1[2];
+                bf[0] = *reinterpret_cast<const uint4*>(hp + 16 * Mma<E>::chunk(0, lh));
+                bf[1] = *reinterpret_cast<const uint4*>(hp + 16 * Mma<E>::chunk(1, lh));
+                a0[0] = *reinterpret_cast<const uint4*>(wb0 + tap9 * PITCH + 16 * Mma<E>::chunk(0, lh));
+                a0[1] = *reinterpret_cast<const uint4*>(wb0 + tap9 * PITCH + 16 * Mma<E>::chunk(1, lh));
+                a1[0] = *reinterpret_cast<const uint4*>(wb1 + tap9 * PITCH + 16 * Mma<E>::chunk(0, lh));
+                a1[1] = *reinterpret_cast<const uint4*>(wb1 + tap9 * PITCH + 16 * Mma<E>::chunk(1, lh));
+                Mma<E>::run(a0, bf, acc[0]);
+                Mma<E>::run(a1, bf, acc[1]);
+            }
+        if (!more) break;
+        advance();
+        __syncthreads();          // everyone is done reading the staged chunk
+        write_lds();
+        __syncthreads();
+        more = dt <= pt;
+    }
+
+    const int h = h0 + wave, w = w0 + lr;
+    if (h >= a.H) return;
+    const long p = ((long)t * a.H + h) * a.W + w;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            store_quad<E>(a, p, co0 + i * 32 + 8 * g + 4 * lh, acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2],
+                          acc[i][4 * g + 3]);
+}
+
+template <typename E, int TH>
+int launch_halo(const ConvArgs& a0, hipStream_t s) {
+    ConvArgs a = a0;
+    a.nCoTiles = cdiv(a.Cout, 64);
+    const int grid = a.T * cdiv(a.H, TH) * (a.W / 32) * a.nCoTiles;
+    const size_t lds = (size_t)(TH + 2) * 34 * 80 + 64 * 9 * 80;
+    hipLaunchKernelGGL((conv3x3_halo_kernel<E, TH>), dim3(grid), dim3(64 * TH), lds, s, a);
+    FLAIR_LAUNCH_CHECK();
+    return FLAIR_OK;
 }
 
 // TC x TP block tile (couts x pixels), 4 waves arranged WC x WP.
@@ -123,14 +335,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const int pt = a.KT / 2, ph = a.KH / 2, pw = a.KW / 2;
 
     uint4 xreg[XR], wreg[WR];
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
 
     // K-loop state (block uniform)
     int tap = 0, seg = 0, cb = 0, segOff = 0;
     int dt = -pt, dh = -ph, dw = -pw;
 
+    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.w, a.wBytes);
+    constexpr unsigned ESZ = sizeof(E);
     auto issue_loads = [&]() {
-        const E* xs = reinterpret_cast<const E*>(a.x[seg]);
+        const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.x[seg], a.segBytes[seg]);
         const int ld = a.segLd[seg];
         const int coff = cb * BKE + chunk * VEC;
 #pragma unroll
@@ -138,22 +351,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             const int t2 = xt[i] + dt, h2 = xh[i] + dh, w2 = xw[i] + dw;
             const bool ok = xvalid[i] && (unsigned)t2 < (unsigned)a.T && (unsigned)h2 < (unsigned)a.H &&
                             (unsigned)w2 < (unsigned)a.W;
-            if (ok) {
-                const long pix = ((long)t2 * a.H + h2) * a.W + w2;
-                xreg[i] = *reinterpret_cast<const uint4*>(xs + pix * ld + coff);
-            } else {
-                xreg[i] = zero4;
-            }
+            const unsigned off = ok ? (unsigned)(((t2 * a.H + h2) * a.W + w2) * ld + coff) * ESZ : FLAIR_OOB;
+            xreg[i] = buf_load16(xr, off);
         }
-        const E* ws = reinterpret_cast<const E*>(a.w);
-        const long kofs = (long)tap * a.CinTot + segOff + coff;
+        const unsigned kofs = (unsigned)(tap * a.CinTot + segOff + coff) * ESZ;
 #pragma unroll
         for (int j = 0; j < WR; ++j) {
             const int n = co0 + srow + 64 * j;
-            if (n < a.Cout)
-                wreg[j] = *reinterpret_cast<const uint4*>(ws + (long)n * taps * a.CinTot + kofs);
-            else
-                wreg[j] = zero4;
+            wreg[j] = buf_load16(wrs, n < a.Cout ? (unsigned)(n * taps * a.CinTot) * ESZ + kofs : FLAIR_OOB);
         }
     };
     auto advance = [&]() {
@@ -235,49 +440,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     }
 
     // ---- epilogue: lane = pixel column, register quad = 4 consecutive couts ----
-    E* y = reinterpret_cast<E*>(a.y);
-    const E* r0 = reinterpret_cast<const E*>(a.res0);
-    const E* r1 = reinterpret_cast<const E*>(a.res1);
 #pragma unroll
     for (int j = 0; j < FP; ++j) {
         const long p = p0 + wp * (TP / WP) + j * 32 + lr;
         if (p >= a.P) continue;
 #pragma unroll
-        for (int i = 0; i < FC; ++i) {
+        for (int i = 0; i < FC; ++i)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int co = co0 + wc * (TC / WC) + i * 32 + 8 * g + 4 * lh;
-                if (co >= a.Cout) continue;  // Cout is a multiple of 4
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
-                if (a.bias) {
-                    const float4 b = *reinterpret_cast<const float4*>(a.bias + co);
-                    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], a.act);
-                if (r0) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += ET<E>::ld(r0 + p * a.res0Ld + co + e);
-                }
-                if (r1) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += ET<E>::ld(r1 + p * a.res1Ld + co + e);
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] *= a.outScale;
-                E* dst = y + p * a.yLd + co;
-                if constexpr (sizeof(E) == 4) {
-                    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-                    uint2 pk;
-                    pk.x = pack2bf(v[0], v[1]);
-                    pk.y = pack2bf(v[2], v[3]);
-                    *reinterpret_cast<uint2*>(dst) = pk;
-                }
-            }
-        }
+            for (int g = 0; g < 4; ++g)
+                store_quad<E>(a, p, co0 + wc * (TC / WC) + i * 32 + 8 * g + 4 * lh, acc[i][j][4 * g],
+                              acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
     }
 }
 
@@ -293,22 +465,32 @@ int launch(const ConvArgs& a0, hipStream_t s) {
     return FLAIR_OK;
 }
 
-// Tile choice: keep >= ~2 workgroups per CU when the problem allows it.
-// 0: 128 couts x 128 pixels, 1: 64 x 128, 2: 64 x 64.
-int choose_variant(long P, int Cout) {
-    const long tiles128 = (long)cdiv(P, 128) * cdiv(Cout, 128);
-    if (Cout > 64 && tiles128 >= 512) return 0;
-    const long tiles64x128 = (long)cdiv(P, 128) * cdiv(Cout, 64);
+// Kernel choice.  3..5: halo kernel with 8/4/2 image rows per workgroup (3x3 spatial taps,
+// W a multiple of 32); 0..2: im2col tiles 128 couts x 128 pixels, 64 x 128, 64 x 64.
+// Either way keep >= ~2 workgroups per CU when the problem allows it.
+int choose_variant(const ConvArgs& a) {
+    if (a.KH == 3 && a.KW == 3 && a.W % 32 == 0 && a.H >= 2) {
+        const long per = (long)a.T * (a.W / 32) * cdiv(a.Cout, 64);
+        if (per * cdiv(a.H, 8) >= 512) return 3;
+        if (per * cdiv(a.H, 4) >= 512) return 4;
+        return 5;
+    }
+    const long tiles128 = (long)cdiv(a.P, 128) * cdiv(a.Cout, 128);
+    if (a.Cout > 64 && tiles128 >= 512) return 0;
+    const long tiles64x128 = (long)cdiv(a.P, 128) * cdiv(a.Cout, 64);
     if (tiles64x128 >= 512) return 1;
     return 2;
 }
 
 template <typename E>
 int dispatch(const ConvArgs& a, hipStream_t s) {
-    switch (choose_variant(a.P, a.Cout)) {
+    switch (choose_variant(a)) {
         case 0: return launch<E, 128, 128, 2, 2>(a, s);
         case 1: return launch<E, 64, 128, 1, 4>(a, s);
-        default: return launch<E, 64, 64, 2, 2>(a, s);
+        case 2: return launch<E, 64, 64, 2, 2>(a, s);
+        case 3: return launch_halo<E, 8>(a, s);
+        case 4: return launch_halo<E, 4>(a, s);
+        default: return launch_halo<E, 2>(a, s);
     }
 }
 
@@ -316,7 +498,10 @@ int dispatch(const ConvArgs& a, hipStream_t s) {
 
 extern "C" int flair_conv_variant(const flair_conv_params* p) {
     if (!p) return -1;
-    return choose_variant((long)p->T * p->H * p->W, p->Cout);
+    ConvArgs a{};
+    a.T = p->T; a.H = p->H; a.W = p->W; a.KT = p->KT; a.KH = p->KH; a.KW = p->KW; a.Cout = p->Cout;
+    a.P = (long)p->T * p->H * p->W;
+    return choose_variant(a);
 }
 
 extern "C" int flair_conv_nhwc(const flair_conv_params* p, const void* const* x, const void* w,
@@ -343,6 +528,15 @@ extern "C" int flair_conv_nhwc(const flair_conv_params* p, const void* const* x,
         a.segC[i] = p->seg_c[i];
         a.segLd[i] = p->seg_ld[i];
         a.CinTot += p->seg_c[i];
+        const unsigned long long bytes =
+            (((unsigned long long)p->T * p->H * p->W - 1) * p->seg_ld[i] + p->seg_c[i]) * esz;
+        FLAIR_CHECK(bytes < 0x80000000ull, "flair_conv_nhwc: segment %d spans %llu bytes (limit 2 GiB)", i, bytes);
+        a.segBytes[i] = (unsigned)bytes;
+    }
+    {
+        const unsigned long long wb = (unsigned long long)p->Cout * p->KT * p->KH * p->KW * a.CinTot * esz;
+        FLAIR_CHECK(wb < 0x80000000ull, "flair_conv_nhwc: weights span %llu bytes (limit 2 GiB)", wb);
+        a.wBytes = (unsigned)wb;
     }
     FLAIR_CHECK(p->y_ld >= p->Cout && (p->y_ld * esz) % 8 == 0 && ((uintptr_t)y) % 16 == 0,
                 "flair_conv_nhwc: output stride/alignment");

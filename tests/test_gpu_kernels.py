@@ -31,6 +31,13 @@ def _ops():
     (5, 6, 6, [64], 8, (1, 1, 1), 3, 0),
     (1, 64, 64, [64, 64, 64, 32], 64, (1, 3, 3), 2, 0),
     (16, 4, 4, [512], 512, (3, 3, 3), 0, 1),
+    # halo kernel (3x3 spatial taps, W % 32 == 0): 8 / 4 / 2 rows per workgroup, 2-D and 3-D
+    (16, 64, 64, [64], 64, (1, 3, 3), 0, 1),
+    (2, 128, 128, [64, 64], 64, (1, 3, 3), 2, 0),
+    (1, 64, 32, [128], 432, (1, 3, 3), 0, 0),
+    (1, 30, 32, [64, 64, 64, 32], 64, (1, 3, 3), 2, 2),
+    (5, 16, 32, [64], 128, (3, 3, 3), 0, 1),
+    (16, 36, 64, [32], 64, (3, 3, 3), 3, 0),
 ])
 def test_conv(dev, dtype, case):
     ops = _ops()
