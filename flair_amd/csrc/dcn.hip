@@ -33,7 +33,7 @@ struct DcnArgs {
     int F, H, W, Cout, G;
     float maxMag;
     long P;
-    int nCoTiles;
+    unsigned xBytes[2], rawBytes, wBytes;
 };
 
 template <typename E> struct MmaD;
@@ -60,154 +60,197 @@ template <> struct MmaD<float> {
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
-// block tile: 64 couts x 64 pixels, 4 waves as 2 x 2 (one 32x32 accumulator each)
-template <typename E>
+__device__ __forceinline__ float fast_tanh(float x) {
+    // 1 - 2/(e^{2x}+1); |err| ~ 1e-7 relative, saturates cleanly for large |x|
+    const float e = __expf(2.f * x);
+    return 1.f - 2.f / (e + 1.f);
+}
+
+// Workgroup = 64 consecutive pixels of one frame x ALL output channels (NCF fragments of 32),
+// so every bilinear gather is done exactly once.  The conv_offset output of the 64 pixels
+// (27*G channels) is staged in LDS once; per K step (one tap, 64 bytes of channels) every
+// thread owns one (pixel, 16-byte channel chunk): it turns the staged raw offsets into 4
+// corner addresses and issues 4 unconditional buffer loads (out-of-range corners read 0)
+// plus its share of the weight tile.  Two register sets alternate, so the loads of step k+1
+// are in flight while step k is blended, written to LDS and multiplied on the matrix cores.
+template <typename E, int NCF>
 __global__ __launch_bounds__(256) void dcn_kernel(DcnArgs a) {
     constexpr int BKE = MmaD<E>::BKE;
     constexpr int VEC = ET<E>::VEC;
-    constexpr int TC = 64, TP = 64;
-    __shared__ __attribute__((aligned(16))) char smem[2 * (TC + TP) * 64];
+    constexpr unsigned ESZ = sizeof(E);
+    constexpr int TC = NCF * 32, TP = 64;
+    constexpr int WR = TC / 64 > 0 ? TC / 64 : 1;             // weight pieces per thread
+    constexpr int PAIRS = NCF / 2;                            // (cout-frag, pixel-frag) pairs per wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int rawC = 27 * a.G;
+    const int rawPitch = ((rawC * (int)ESZ + 15) / 16) * 16 + 16;   // +16 B: spreads pixels over banks
+    char* sraw = smem;
+    char* stile = smem + TP * rawPitch;
     constexpr int BUF = (TC + TP) * 64;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wc = wave >> 1, wp = wave & 1;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int coTile = bid % a.nCoTiles;
-    const long p0 = (long)(bid / a.nCoTiles) * TP;
-    const int co0 = coTile * TC;
-
-    const int chunk = tid & 3, srow = tid >> 2;
+    const int lr = lane & 31, lh = lane >> 5;
+    const long p0 = (long)blockIdx.x * TP;
+    const int q = tid & 3, srow = tid >> 2;
     long p = p0 + srow;
     const bool pvalid = p < a.P;
-    if (!pvalid) p = 0;
+    if (!pvalid) p = a.P - 1;
     const int pw = (int)(p % a.W);
     const int ph = (int)((p / a.W) % a.H);
-    const long pf = p / ((long)a.W * a.H);
+    const int pf = (int)(p / ((long)a.W * a.H));
     float2 fl1 = make_float2(0.f, 0.f), fl2 = make_float2(0.f, 0.f);
     if (a.flow1) fl1 = *reinterpret_cast<const float2*>(a.flow1 + p * 2);
     if (a.flow2) fl2 = *reinterpret_cast<const float2*>(a.flow2 + p * 2);
-    const E* rawp = reinterpret_cast<const E*>(a.raw) + p * a.rawLd;
+
+    // ---- stage the raw conv_offset rows of the 64 pixels (16-byte pieces, coalesced)
+    {
+        const int piecesPerPix = (rawC * (int)ESZ + 15) / 16;
+        const __amdgpu_buffer_rsrc_t rr = make_rsrc(a.raw, a.rawBytes);
+        for (int id = tid; id < TP * piecesPerPix; id += 256) {
+            const int px = id / piecesPerPix, pc = id % piecesPerPix;
+            const long pp = p0 + px;
+            const unsigned off = pp < a.P ? (unsigned)(pp * a.rawLd * ESZ) + pc * 16 : FLAIR_OOB;
+            *reinterpret_cast<uint4*>(sraw + px * rawPitch + pc * 16) = buf_load16(rr, off);
+        }
+    }
+    __syncthreads();
+    const E* myraw = reinterpret_cast<const E*>(sraw + srow * rawPitch);
+
     const int cpg = a.Cin / a.G;
     const int halfC = a.Cin / 2;
-
-    uint4 xreg, wreg;
-    int tap = 0, cb = 0;
     const int cbPerTap = a.Cin / BKE;
+    const int nk = 9 * cbPerTap;
+    const __amdgpu_buffer_rsrc_t xr0 = make_rsrc(a.x[0], a.xBytes[0]);
+    const __amdgpu_buffer_rsrc_t xr1 = make_rsrc(a.x[1], a.xBytes[1]);
+    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.w, a.wBytes);
+    const unsigned frameBase = (unsigned)pf * a.H * a.W;
 
-    auto issue = [&]() {
-        const int c = cb * BKE + chunk * VEC;
+    struct Regs {
+        uint4 c[4];
+        uint4 w[WR];
+        float wt[4];
+    } rs[2];
+
+    auto issue = [&](Regs& r, int k) {
+        const int tap = k / cbPerTap, cb = k % cbPerTap;
+        const int c = cb * BKE + q * VEC;
+        const int g = c / cpg;
+        const int o = g * 9 + tap;
+        const float ry = ET<E>::ld(myraw + 2 * o), rx = ET<E>::ld(myraw + 2 * o + 1);
+        const float rm = ET<E>::ld(myraw + 18 * a.G + o);
+        const float2 fl = g < a.G / 2 ? fl1 : fl2;
+        const float sy = (float)(ph - 1 + tap / 3) + a.maxMag * fast_tanh(ry) + fl.y;
+        const float sx = (float)(pw - 1 + tap % 3) + a.maxMag * fast_tanh(rx) + fl.x;
+        const float mk = 1.f / (1.f + __expf(-rm));
+        const float fy = floorf(sy), fx = floorf(sx);
+        const float ay = sy - fy, ax = sx - fx;
+        // clamp before the int conversion so wild offsets cannot overflow
+        const int y0 = (int)fminf(fmaxf(fy, -2.f), (float)a.H), x0 = (int)fminf(fmaxf(fx, -2.f), (float)a.W);
+        r.wt[0] = (1.f - ay) * (1.f - ax) * mk;
+        r.wt[1] = (1.f - ay) * ax * mk;
+        r.wt[2] = ay * (1.f - ax) * mk;
+        r.wt[3] = ay * ax * mk;
+        const bool second = cb * BKE >= halfC;                // block-uniform (halfC % BKE == 0)
+        const unsigned ld = (unsigned)(second ? a.xLd[1] : a.xLd[0]) * ESZ;
+        const unsigned coff = (unsigned)(c - (second ? halfC : 0)) * ESZ;
+        const __amdgpu_buffer_rsrc_t xr = second ? xr1 : xr0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int yy = y0 + (i >> 1), xx = x0 + (i & 1);
+            const bool ok = pvalid && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+            r.c[i] = buf_load16(xr, ok ? (frameBase + (unsigned)(yy * a.W + xx)) * ld + coff : FLAIR_OOB);
+        }
+#pragma unroll
+        for (int j = 0; j < WR; ++j) {
+            const int n = srow + 64 * j;
+            r.w[j] = buf_load16(wrs, n < a.Cout && n < TC ? (unsigned)((n * 9 + tap) * a.Cin + c) * ESZ : FLAIR_OOB);
+        }
+    };
+    auto blend_and_stage = [&](const Regs& r, int buf) {
         float acc[VEC];
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
-        if (pvalid) {
-            const int g = c / cpg;
-            const int o = g * 9 + tap;
-            const float ry = ET<E>::ld(rawp + 2 * o), rx = ET<E>::ld(rawp + 2 * o + 1);
-            const float rm = ET<E>::ld(rawp + 18 * a.G + o);
-            const float2 fl = g < a.G / 2 ? fl1 : fl2;
-            const float dy = a.maxMag * tanhf(ry) + fl.y;
-            const float dx = a.maxMag * tanhf(rx) + fl.x;
-            const float mk = 1.f / (1.f + __expf(-rm));
-            const float sy = (float)(ph - 1 + tap / 3) + dy;
-            const float sx = (float)(pw - 1 + tap % 3) + dx;
-            if (sy > -1.f && sx > -1.f && sy < (float)a.H && sx < (float)a.W) {
-                const float fy = floorf(sy), fx = floorf(sx);
-                const int y0 = (int)fy, x0 = (int)fx;
-                const float ay = sy - fy, ax = sx - fx;
-                const float wgt[4] = {(1.f - ay) * (1.f - ax), (1.f - ay) * ax, ay * (1.f - ax), ay * ax};
-                const int seg = c >= halfC;
-                const E* xb = reinterpret_cast<const E*>(a.x[seg]) + (c - seg * halfC);
-                const int ld = a.xLd[seg];
-                const long fb = pf * a.H * a.W;
+        for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int yy = y0 + (q >> 1), xx = x0 + (q & 1);
-                    if ((unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W) {
-                        float v[VEC];
-                        Vec16<E>::load(xb + (fb + (long)yy * a.W + xx) * ld, v);
+        for (int i = 0; i < 4; ++i) {
+            float v[VEC];
+            Vec16<E>::load(reinterpret_cast<const E*>(&r.c[i]), v);
 #pragma unroll
-                        for (int k = 0; k < VEC; ++k) acc[k] = fmaf(wgt[q], v[k], acc[k]);
-                    }
-                }
+            for (int e = 0; e < VEC; ++e) acc[e] = fmaf(r.wt[i], v[e], acc[e]);
+        }
+        char* base = stile + buf * BUF;
+        alignas(16) E out[VEC];
+        Vec16<E>::store(out, acc);
+        *reinterpret_cast<uint4*>(base + TC * 64 + lds_off(srow, q)) = *reinterpret_cast<const uint4*>(out);
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) acc[k] *= mk;
-            }
-        }
-        if constexpr (sizeof(E) == 4) {
-            xreg = make_uint4(__float_as_uint(acc[0]), __float_as_uint(acc[1]), __float_as_uint(acc[2]),
-                              __float_as_uint(acc[3]));
-        } else {
-            xreg = make_uint4(pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]), pack2bf(acc[4], acc[5]),
-                              pack2bf(acc[6], acc[7]));
-        }
-        const int n = co0 + srow;
-        if (n < a.Cout)
-            wreg = *reinterpret_cast<const uint4*>(reinterpret_cast<const E*>(a.w) + ((long)n * 9 + tap) * a.Cin + c);
-        else
-            wreg = make_uint4(0, 0, 0, 0);
-    };
-    auto advance = [&]() {
-        if (++cb == cbPerTap) {
-            cb = 0;
-            ++tap;
-        }
-    };
-    auto write_lds = [&](int buf) {
-        char* base = smem + buf * BUF;
-        *reinterpret_cast<uint4*>(base + lds_off(srow, chunk)) = wreg;
-        *reinterpret_cast<uint4*>(base + TC * 64 + lds_off(srow, chunk)) = xreg;
+        for (int j = 0; j < WR; ++j)
+            if (srow + 64 * j < TC) *reinterpret_cast<uint4*>(base + lds_off(srow + 64 * j, q)) = r.w[j];
     };
 
-    f32x16 acc;
+    f32x16 acc[PAIRS];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const int nk = 9 * cbPerTap;
-    const int lr = lane & 31, lh = lane >> 5;
-    issue();
-    advance();
-    write_lds(0);
-    __syncthreads();
-    for (int ks = 0; ks < nk; ++ks) {
-        const int cur = ks & 1;
-        const bool more = ks + 1 < nk;
-        if (more) {
-            issue();
-            advance();
+    for (int i = 0; i < PAIRS; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const int pfrag = wave & 1;               // which 32-pixel half this wave multiplies
+    const int cf0 = (wave >> 1) * PAIRS;      // first cout fragment of this wave
+
+    issue(rs[0], 0);
+    for (int k = 0; k < nk; k += 2) {
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+            const int kk = k + par;
+            if (kk + 1 < nk) issue(rs[par ^ 1], kk + 1);
+            blend_and_stage(rs[par], par);
+            __syncthreads();
+            const char* wb = stile + par * BUF;
+            const char* xb = wb + TC * 64;
+            uint4 bf[2];
+            bf[0] = *reinterpret_cast<const uint4*>(xb + lds_off(pfrag * 32 + lr, MmaD<E>::chunk(0, lh)));
+            bf[1] = *reinterpret_cast<const uint4*>(xb + lds_off(pfrag * 32 + lr, MmaD<E>::chunk(1, lh)));
+#pragma unroll
+            for (int i = 0; i < PAIRS; ++i) {
+                uint4 af[2];
+                af[0] = *reinterpret_cast<const uint4*>(wb + lds_off((cf0 + i) * 32 + lr, MmaD<E>::chunk(0, lh)));
+                af[1] = *reinterpret_cast<const uint4*>(wb + lds_off((cf0 + i) * 32 + lr, MmaD<E>::chunk(1, lh)));
+                MmaD<E>::run(af, bf, acc[i]);
+            }
         }
-        const char* wb = smem + cur * BUF;
-        const char* xb = wb + TC * 64;
-        uint4 af[2], bf[2];
-        af[0] = *reinterpret_cast<const uint4*>(wb + lds_off(wc * 32 + lr, MmaD<E>::chunk(0, lh)));
-        af[1] = *reinterpret_cast<const uint4*>(wb + lds_off(wc * 32 + lr, MmaD<E>::chunk(1, lh)));
-        bf[0] = *reinterpret_cast<const uint4*>(xb + lds_off(wp * 32 + lr, MmaD<E>::chunk(0, lh)));
-        bf[1] = *reinterpret_cast<const uint4*>(xb + lds_off(wp * 32 + lr, MmaD<E>::chunk(1, lh)));
-        MmaD<E>::run(af, bf, acc);
-        if (more) write_lds(cur ^ 1);
-        __syncthreads();
     }
-    const long po = p0 + wp * 32 + lr;
+    const long po = p0 + pfrag * 32 + lr;
     if (po >= a.P) return;
     E* y = reinterpret_cast<E*>(a.y);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int co = co0 + wc * 32 + 8 * g + 4 * lh;
-        if (co >= a.Cout) continue;
-        float v[4];
+    for (int i = 0; i < PAIRS; ++i)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[4 * g + e] + (a.bias ? a.bias[co + e] : 0.f);
-        E* dst = y + po * a.yLd + co;
-        if constexpr (sizeof(E) == 4) {
-            *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-            uint2 pk;
-            pk.x = pack2bf(v[0], v[1]);
-            pk.y = pack2bf(v[2], v[3]);
-            *reinterpret_cast<uint2*>(dst) = pk;
+        for (int g = 0; g < 4; ++g) {
+            const int co = (cf0 + i) * 32 + 8 * g + 4 * lh;
+            if (co >= a.Cout) continue;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][4 * g + e] + (a.bias ? a.bias[co + e] : 0.f);
+            E* dst = y + po * a.yLd + co;
+            if constexpr (sizeof(E) == 4) {
+                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                uint2 pk;
+                pk.x = pack2bf(v[0], v[1]);
+                pk.y = pack2bf(v[2], v[3]);
+                *reinterpret_cast<uint2*>(dst) = pk;
+            }
         }
-    }
 }
 
 }  // namespace
+
+template <typename E, int NCF>
+static int launch_dcn(const DcnArgs& a, hipStream_t stream) {
+    const int esz = (int)sizeof(E);
+    const int rawPitch = ((27 * a.G * esz + 15) / 16) * 16 + 16;
+    const size_t lds = (size_t)64 * rawPitch + 2 * (NCF * 32 + 64) * 64;
+    hipLaunchKernelGGL((dcn_kernel<E, NCF>), dim3(cdiv(a.P, 64)), dim3(256), lds, stream, a);
+    FLAIR_LAUNCH_CHECK();
+    return FLAIR_OK;
+}
 
 extern "C" int flair_dcn_align(const flair_dcn_params* p, const void* x0, const void* x1, const void* raw,
                                const float* flow1, const float* flow2, const void* w, const float* bias, void* y,
@@ -215,22 +258,26 @@ extern "C" int flair_dcn_align(const flair_dcn_params* p, const void* x0, const 
     FLAIR_CHECK(p && x0 && x1 && raw && w && y, "flair_dcn_align: null argument");
     FLAIR_CHECK(p->dtype == FLAIR_F32 || p->dtype == FLAIR_BF16, "flair_dcn_align: bad dtype");
     const int vec = p->dtype == FLAIR_BF16 ? 8 : 4, bke = p->dtype == FLAIR_BF16 ? 32 : 16;
+    const int esz = p->dtype == FLAIR_BF16 ? 2 : 4;
     FLAIR_CHECK(p->G > 0 && p->G % 2 == 0 && p->Cin % p->G == 0 && (p->Cin / p->G) % vec == 0 &&
                     (p->Cin / 2) % bke == 0,
                 "flair_dcn_align: Cin=%d G=%d not supported", p->Cin, p->G);
-    FLAIR_CHECK(p->Cout % 4 == 0 && p->raw_ld >= 27 * p->G, "flair_dcn_align: Cout / raw_ld");
+    FLAIR_CHECK(p->Cout % 4 == 0 && p->Cout <= 128 && p->raw_ld >= 27 * p->G && (p->raw_ld * esz) % 16 == 0,
+                "flair_dcn_align: Cout (<=128) / raw_ld");
     DcnArgs a;
     a.x[0] = x0; a.x[1] = x1; a.xLd[0] = p->x_ld[0]; a.xLd[1] = p->x_ld[1];
     a.Cin = p->Cin; a.raw = raw; a.rawLd = p->raw_ld; a.flow1 = flow1; a.flow2 = flow2;
     a.w = w; a.bias = bias; a.y = y; a.yLd = p->y_ld;
     a.F = p->F; a.H = p->H; a.W = p->W; a.Cout = p->Cout; a.G = p->G; a.maxMag = p->max_residue_magnitude;
     a.P = (long)p->F * p->H * p->W;
-    a.nCoTiles = cdiv(p->Cout, 64);
-    const int grid = cdiv(a.P, 64) * a.nCoTiles;
+    const unsigned long long half = p->Cin / 2;
+    const unsigned long long b0 = ((unsigned long long)(a.P - 1) * p->x_ld[0] + half) * esz;
+    const unsigned long long b1 = ((unsigned long long)(a.P - 1) * p->x_ld[1] + half) * esz;
+    const unsigned long long br = ((unsigned long long)(a.P - 1) * p->raw_ld + 27 * p->G) * esz;
+    FLAIR_CHECK(b0 < 0x80000000ull && b1 < 0x80000000ull && br < 0x80000000ull, "flair_dcn_align: tensor spans >= 2 GiB");
+    a.xBytes[0] = (unsigned)b0; a.xBytes[1] = (unsigned)b1; a.rawBytes = (unsigned)((br + 15) / 16 * 16);
+    a.wBytes = (unsigned)((unsigned long long)p->Cout * 9 * p->Cin * esz);
     if (p->dtype == FLAIR_BF16)
-        hipLaunchKernelGGL(dcn_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, a);
-    else
-        hipLaunchKernelGGL(dcn_kernel<float>, dim3(grid), dim3(256), 0, stream, a);
-    FLAIR_LAUNCH_CHECK();
-    return FLAIR_OK;
+        return p->Cout <= 64 ? launch_dcn<bf16_t, 2>(a, stream) : launch_dcn<bf16_t, 4>(a, stream);
+    return p->Cout <= 64 ? launch_dcn<float, 2>(a, stream) : launch_dcn<float, 4>(a, stream);
 }
