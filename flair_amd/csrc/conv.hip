@@ -45,6 +45,8 @@ struct ConvArgs {
     int nPixTiles, nCoTiles;
     unsigned segBytes[4];  // addressable bytes of each input segment / of the weights
     unsigned wBytes;
+    float* part;           // split-K: f32 partial sums [splitK][P][Cout] (null when splitK == 1)
+    int splitK;
 };
 
 template <typename E> struct Mma;
@@ -336,9 +338,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 
     uint4 xreg[XR], wreg[WR];
 
-    // K-loop state (block uniform)
-    int tap = 0, seg = 0, cb = 0, segOff = 0;
-    int dt = -pt, dh = -ph, dw = -pw;
+    // K-loop state (block uniform); with split-K, blockIdx.y owns steps [ks0, ks1)
+    const int nkAll = taps * (a.CinTot / BKE);
+    const int ks0 = (int)((long)blockIdx.y * nkAll / a.splitK);
+    const int ks1 = (int)((long)(blockIdx.y + 1) * nkAll / a.splitK);
+    int tap = ks0 / (a.CinTot / BKE), seg = 0, cb = ks0 % (a.CinTot / BKE), segOff = 0;
+    while (cb * BKE >= a.segC[seg]) {
+        cb -= a.segC[seg] / BKE;
+        segOff += a.segC[seg];
+        ++seg;
+    }
+    int dw = tap % a.KW - pw, dh = (tap / a.KW) % a.KH - ph, dt = tap / (a.KW * a.KH) - pt;
 
     const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.w, a.wBytes);
     constexpr unsigned ESZ = sizeof(E);
@@ -401,7 +411,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = taps * (a.CinTot / BKE);
+    const int nk = ks1 - ks0;
     const int lr = lane & 31, lh = lane >> 5;
 
     issue_loads();
@@ -440,6 +450,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     }
 
     // ---- epilogue: lane = pixel column, register quad = 4 consecutive couts ----
+    if (a.splitK > 1) {   // raw f32 partials; bias/act/residual happen in the reduce kernel
+#pragma unroll
+        for (int j = 0; j < FP; ++j) {
+            const long p = p0 + wp * (TP / WP) + j * 32 + lr;
+            if (p >= a.P) continue;
+#pragma unroll
+            for (int i = 0; i < FC; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co = co0 + wc * (TC / WC) + i * 32 + 8 * g + 4 * lh;
+                    if (co < a.Cout)
+                        *reinterpret_cast<float4*>(a.part + ((long)blockIdx.y * a.P + p) * a.Cout + co) =
+                            make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2],
+                                        acc[i][j][4 * g + 3]);
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < FP; ++j) {
         const long p = p0 + wp * (TP / WP) + j * 32 + lr;
@@ -453,6 +481,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     }
 }
 
+// split-K reduce: sum the f32 partials, then the usual epilogue
+template <typename E>
+__global__ void conv_splitk_reduce_kernel(ConvArgs a) {
+    const long quads = a.P * (a.Cout / 4);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < quads; i += (long)gridDim.x * blockDim.x) {
+        const long p = i / (a.Cout / 4);
+        const int co = (int)(i % (a.Cout / 4)) * 4;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < a.splitK; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(a.part + ((long)k * a.P + p) * a.Cout + co);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        store_quad<E>(a, p, co, s.x, s.y, s.z, s.w);
+    }
+}
+
 template <typename E, int TC, int TP, int WC, int WP>
 int launch(const ConvArgs& a0, hipStream_t s) {
     ConvArgs a = a0;
@@ -460,9 +504,29 @@ int launch(const ConvArgs& a0, hipStream_t s) {
     a.nCoTiles = cdiv(a.Cout, TC);
     const int grid = a.nPixTiles * a.nCoTiles;
     const size_t lds = 2 * (TC + TP) * 64;
-    hipLaunchKernelGGL((conv_igemm_kernel<E, TC, TP, WC, WP>), dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<E, TC, TP, WC, WP>), dim3(grid, a.splitK), dim3(256), lds, s, a);
     FLAIR_LAUNCH_CHECK();
+    if (a.splitK > 1) {
+        long g = (a.P * (a.Cout / 4) + 255) / 256;
+        if (g > 2048) g = 2048;
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel<E>, dim3((int)g), dim3(256), 0, s, a);
+        FLAIR_LAUNCH_CHECK();
+    }
     return FLAIR_OK;
+}
+
+// Split-K factor for the im2col path: deep-K convolutions on few pixels (the 16x16 .. 4x4
+// levels: K up to 13,824, <= 256 tiles) would otherwise run one long serial K loop per CU.
+int choose_split(const ConvArgs& a, int variant) {
+    if (variant != 2) return 1;
+    const int bke = 64 / (a.wBytes && a.CinTot ? (int)(a.wBytes / ((unsigned long long)a.Cout * a.KT * a.KH * a.KW * a.CinTot)) : 2);
+    const long nk = (long)a.KT * a.KH * a.KW * (a.CinTot / bke);
+    const long tiles = (long)cdiv(a.P, 64) * cdiv(a.Cout, 64);
+    if (tiles >= 384 || nk < 32) return 1;
+    long s = 1024 / tiles;
+    if (s > 16) s = 16;
+    if (s > nk / 8) s = nk / 8;
+    return s < 1 ? 1 : (int)s;
 }
 
 // Kernel choice.  3..5: halo kernel with 8/4/2 image rows per workgroup (3x3 spatial taps,
@@ -483,8 +547,11 @@ int choose_variant(const ConvArgs& a) {
 }
 
 template <typename E>
-int dispatch(const ConvArgs& a, hipStream_t s) {
-    switch (choose_variant(a)) {
+int dispatch(const ConvArgs& a0, hipStream_t s) {
+    ConvArgs a = a0;
+    const int variant = choose_variant(a);
+    a.splitK = a.part ? choose_split(a, variant) : 1;
+    switch (variant) {
         case 0: return launch<E, 128, 128, 2, 2>(a, s);
         case 1: return launch<E, 64, 128, 1, 4>(a, s);
         case 2: return launch<E, 64, 64, 2, 2>(a, s);
@@ -496,17 +563,28 @@ int dispatch(const ConvArgs& a, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int flair_conv_variant(const flair_conv_params* p) {
-    if (!p) return -1;
-    ConvArgs a{};
+extern "C" int flair_conv_variant(const flair_conv_params* p);
+
+static void fill_geometry(ConvArgs& a, const flair_conv_params* p) {
     a.T = p->T; a.H = p->H; a.W = p->W; a.KT = p->KT; a.KH = p->KH; a.KW = p->KW; a.Cout = p->Cout;
     a.P = (long)p->T * p->H * p->W;
-    return choose_variant(a);
+    a.CinTot = 0;
+    for (int i = 0; i < p->nseg && i < 4; ++i) a.CinTot += p->seg_c[i];
+    const int esz = p->dtype == FLAIR_BF16 ? 2 : 4;
+    a.wBytes = (unsigned)((unsigned long long)p->Cout * p->KT * p->KH * p->KW * a.CinTot * esz);
+}
+
+extern "C" size_t flair_conv_workspace_bytes(const flair_conv_params* p) {
+    if (!p) return 0;
+    ConvArgs a{};
+    fill_geometry(a, p);
+    const int split = choose_split(a, choose_variant(a));
+    return split > 1 ? (size_t)split * a.P * a.Cout * sizeof(float) : 0;
 }
 
 extern "C" int flair_conv_nhwc(const flair_conv_params* p, const void* const* x, const void* w,
                                const float* bias, const void* res0, const void* res1, void* y,
-                               hipStream_t stream) {
+                               void* workspace, size_t workspace_bytes, hipStream_t stream) {
     FLAIR_CHECK(p && x && w && y, "flair_conv_nhwc: null argument");
     FLAIR_CHECK(p->dtype == FLAIR_F32 || p->dtype == FLAIR_BF16, "flair_conv_nhwc: bad dtype %d", p->dtype);
     FLAIR_CHECK(p->nseg >= 1 && p->nseg <= 4, "flair_conv_nhwc: nseg %d not in 1..4", p->nseg);
@@ -557,6 +635,19 @@ extern "C" int flair_conv_nhwc(const flair_conv_params* p, const void* const* x,
     a.act = p->act;
     a.outScale = p->out_scale;
     a.P = (long)p->T * p->H * p->W;
+    a.part = nullptr;
+    a.splitK = 1;
+    if (workspace && workspace_bytes >= flair_conv_workspace_bytes(p) && flair_conv_workspace_bytes(p) > 0) {
+        FLAIR_CHECK(((uintptr_t)workspace) % 16 == 0, "flair_conv_nhwc: workspace alignment");
+        a.part = reinterpret_cast<float*>(workspace);
+    }
     if (p->dtype == FLAIR_BF16) return dispatch<bf16_t>(a, stream);
     return dispatch<float>(a, stream);
+}
+
+extern "C" int flair_conv_variant(const flair_conv_params* p) {
+    if (!p) return -1;
+    ConvArgs a{};
+    fill_geometry(a, p);
+    return choose_variant(a);
 }

@@ -123,8 +123,10 @@ def conv(xs, weight, bias, cout, kernel, *, out=None, act=ACT_NONE, res0=None, r
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
+    wsb = _conv_ws_bytes(p)
+    ws = _workspace(wsb, x0.device, "conv") if wsb else None
     check(lib().flair_conv_nhwc(ctypes.byref(p), arr, ptr(weight), ptr(_f32(bias)), ptr(res0),
-                                ptr(res1), ptr(out), stream()), "flair_conv_nhwc")
+                                ptr(res1), ptr(out), ptr(ws), ctypes.c_size_t(wsb), stream()), "flair_conv_nhwc")
     if prof is not None:
         e1.record()
         cin = sum(x.shape[3] for x in xs)
@@ -135,6 +137,12 @@ def conv(xs, weight, bias, cout, kernel, *, out=None, act=ACT_NONE, res0=None, r
 
 # bench.py sets this to a list to time every conv launch with HIP events (roofline leg)
 CONV_PROFILE = None
+
+
+def _conv_ws_bytes(p):
+    f = lib().flair_conv_workspace_bytes
+    f.restype = ctypes.c_size_t
+    return f(ctypes.byref(p))
 
 
 def pack_conv_weight(w, seg_channels, dtype, cout_pad=None):
@@ -166,8 +174,8 @@ def pack_conv_weight(w, seg_channels, dtype, cout_pad=None):
 _gn_ws = {}
 
 
-def _workspace(nbytes, device):
-    key = (device, torch.cuda.current_stream().cuda_stream)
+def _workspace(nbytes, device, tag="gn"):
+    key = (tag, device, torch.cuda.current_stream().cuda_stream)
     buf = _gn_ws.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)

@@ -66,7 +66,10 @@ int flair_abi_version(void);
  *            th.cat (seg_c[i] must be a multiple of 32 (bf16) / 16 (f32); pad with zeros)
  *   w      : [Cout][KT*KH*KW][sum seg_c] in the activation dtype
  *   bias   : [Cout] f32 or NULL;  res0/res1: [T][H][W][Cout-slice] or NULL
- *   y      : [T][H][W] pixels, y_ld elements apart, Cout (multiple of 4) written per pixel */
+ *   y      : [T][H][W] pixels, y_ld elements apart, Cout (multiple of 4) written per pixel
+ *   workspace : optional device scratch of flair_conv_workspace_bytes(p) bytes; when given,
+ *            deep-K convolutions on few pixels (the 16x16..4x4 levels) are split over K
+ *            (f32 partial sums + a reduce/epilogue launch) */
 typedef struct {
     int dtype;
     int T, H, W;
@@ -81,11 +84,13 @@ typedef struct {
     float out_scale;
 } flair_conv_params;
 
+size_t flair_conv_workspace_bytes(const flair_conv_params* p);
 int flair_conv_nhwc(const flair_conv_params* p, const void* const* x, const void* w,
                     const float* bias, const void* res0, const void* res1, void* y,
-                    hipStream_t stream);
-/* Which tile variant flair_conv_nhwc launches for these parameters (profiling aid):
- * 0 = 128 couts x 128 pixels, 1 = 64 x 128, 2 = 64 x 64 per workgroup. */
+                    void* workspace, size_t workspace_bytes, hipStream_t stream);
+/* Which kernel variant flair_conv_nhwc launches for these parameters (profiling aid):
+ * im2col tiles 0 = 128 couts x 128 pixels, 1 = 64 x 128, 2 = 64 x 64 per workgroup;
+ * halo kernel (3x3 spatial taps, W % 32 == 0) 3 / 4 / 5 = 8 / 4 / 2 image rows per workgroup. */
 int flair_conv_variant(const flair_conv_params* p);
 
 
