@@ -128,11 +128,12 @@ __device__ __forceinline__ void store_quad(const ConvArgs& a, long p, int co, fl
 // 64 couts = two A fragments.  Pixel pitch 80 B and weight row pitch 80 B make every
 // ds_read_b128 conflict-free (odd multiples of 16 B).  Loads of chunk k+1 are issued before
 // the MFMAs of chunk k (register staging), written after a barrier.
-template <typename E, int TH>
-__global__ __launch_bounds__(64 * TH) void conv3x3_halo_kernel(ConvArgs a) {
+template <typename E, int TH, int RPW, int PF>
+__global__ __launch_bounds__(64 * TH / RPW, (2 * 64 * TH / RPW + 255) / 256)  // two workgroups per CU
+void conv3x3_halo_kernel(ConvArgs a) {
     constexpr int BKE = Mma<E>::BKE;
     constexpr int VEC = ET<E>::VEC;
-    constexpr int NT = 64 * TH;
+    constexpr int NT = 64 * TH / RPW;              // one wavefront per RPW image rows
     constexpr int HW_ = 34;                        // halo width (32 + 2)
     constexpr int PITCH = 80;                      // bytes per staged pixel / weight row
     constexpr int HALO_PIECES = (TH + 2) * HW_ * 4;
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(64 * TH) void conv3x3_halo_kernel(ConvArgs a) {
     const int taps = a.KT * 9;
     const int pt = a.KT / 2;
 
-    uint4 hreg[HI], wreg[WI];
+    uint4 hreg[PF][HI], wreg[PF][WI];              // PF register sets = prefetch depth in chunks
     int dt = -pt, seg = 0, cb = 0, segOff = 0;
     // skip temporal taps that fall outside the clip (block-uniform)
     auto dt_valid = [&](int d) { return (unsigned)(t + d) < (unsigned)a.T; };
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(64 * TH) void conv3x3_halo_kernel(ConvArgs a) {
         woff[i] = ok ? (unsigned)(((co0 + co) * taps + tap9) * a.CinTot + (id & 3) * VEC) * ESZ : FLAIR_OOB;
     }
 
-    auto issue = [&]() {
+    auto issue = [&](uint4 (&hr)[HI], uint4 (&wr)[WI]) {
         const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.x[seg], a.segBytes[seg]);
         const unsigned ld = (unsigned)a.segLd[seg] * ESZ;
         const int fbase = (t + dt) * a.H * a.W;
@@ -197,11 +198,11 @@ __global__ __launch_bounds__(64 * TH) void conv3x3_halo_kernel(ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < HI; ++i) {
             const unsigned off = hpix[i] >= 0 ? (unsigned)(fbase + hpix[i]) * ld + cofs + hq[i] : FLAIR_OOB;
-            hreg[i] = buf_load16(xr, off);
+            hr[i] = buf_load16(xr, off);
         }
         const unsigned kofs = (unsigned)((dt + pt) * 9 * a.CinTot + segOff + cb * BKE) * ESZ;
 #pragma unroll
-        for (int i = 0; i < WI; ++i) wreg[i] = buf_load16(wrs, woff[i] == FLAIR_OOB ? FLAIR_OOB : woff[i] + kofs);
+        for (int i = 0; i < WI; ++i) wr[i] = buf_load16(wrs, woff[i] == FLAIR_OOB ? FLAIR_OOB : woff[i] + kofs);
     };
     auto advance = [&]() {   // the K loop is exhausted when dt > pt
         ++cb;
@@ -216,78 +217,111 @@ __global__ __launch_bounds__(64 * TH) void conv3x3_halo_kernel(ConvArgs a) {
             }
         }
     };
-    auto write_lds = [&]() {
+    auto write_lds = [&](const uint4 (&hr)[HI], const uint4 (&wr)[WI]) {
 #pragma unroll
         for (int i = 0; i < HI; ++i) {
             const int id = i * NT + tid;
-            if (id < HALO_PIECES) *reinterpret_cast<uint4*>(sh + (id >> 2) * PITCH + (id & 3) * 16) = hreg[i];
+            if (id < HALO_PIECES) *reinterpret_cast<uint4*>(sh + (id >> 2) * PITCH + (id & 3) * 16) = hr[i];
         }
 #pragma unroll
         for (int i = 0; i < WI; ++i) {
             const int id = i * NT + tid;
-            if (id < W_PIECES) *reinterpret_cast<uint4*>(sw + (id >> 2) * PITCH + (id & 3) * 16) = wreg[i];
+            if (id < W_PIECES) *reinterpret_cast<uint4*>(sw + (id >> 2) * PITCH + (id & 3) * 16) = wr[i];
         }
     };
+    // number of K chunks this workgroup walks (temporal taps outside the clip are skipped)
+    int nValidDt = 0;
+    for (int d = -pt; d <= pt; ++d) nValidDt += dt_valid(d) ? 1 : 0;
+    const int nch = nValidDt * (a.CinTot / BKE);
 
-    f32x16 acc[2];
+    f32x16 acc[RPW][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < RPW; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
 
-    issue();
-    advance();
-    write_lds();
-    __syncthreads();
-    bool more = dt <= pt;
-    while (true) {
-        if (more) issue();
-        // ---- 9 taps x 2 k-steps out of LDS
-        const char* hb = sh + ((wave * HW_) + lr) * PITCH;
+    auto compute = [&]() {
+        // ---- 9 taps x 2 k-steps out of LDS; the two weight fragments are reused by RPW rows
+        const char* hb = sh + ((wave * RPW * HW_) + lr) * PITCH;
         const char* wb0 = sw + (lr * 9) * PITCH;
         const char* wb1 = sw + ((lr + 32) * 9) * PITCH;
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
-                const char* hp = hb + (kh * HW_ + kw) * PITCH;
                 const int tap9 = kh * 3 + kw;
-                uint4 bf[2], a0[2], a1[2];
-                bf[0] = *reinterpret_cast<const uint4*>(hp + 16 * Mma<E>::chunk(0, lh));
-                bf[1] = *reinterpret_cast<const uint4*>(hp + 16 * Mma<E>::chunk(1, lh));
+                uint4 a0[2], a1[2];
                 a0[0] = *reinterpret_cast<const uint4*>(wb0 + tap9 * PITCH + 16 * Mma<E>::chunk(0, lh));
                 a0[1] = *reinterpret_cast<const uint4*>(wb0 + tap9 * PITCH + 16 * Mma<E>::chunk(1, lh));
                 a1[0] = *reinterpret_cast<const uint4*>(wb1 + tap9 * PITCH + 16 * Mma<E>::chunk(0, lh));
                 a1[1] = *reinterpret_cast<const uint4*>(wb1 + tap9 * PITCH + 16 * Mma<E>::chunk(1, lh));
-                Mma<E>::run(a0, bf, acc[0]);
-                Mma<E>::run(a1, bf, acc[1]);
+#pragma unroll
+                for (int j = 0; j < RPW; ++j) {
+                    const char* hp = hb + ((j + kh) * HW_ + kw) * PITCH;
+                    uint4 bf[2];
+                    bf[0] = *reinterpret_cast<const uint4*>(hp + 16 * Mma<E>::chunk(0, lh));
+                    bf[1] = *reinterpret_cast<const uint4*>(hp + 16 * Mma<E>::chunk(1, lh));
+                    Mma<E>::run(a0, bf, acc[j][0]);
+                    Mma<E>::run(a1, bf, acc[j][1]);
+                }
             }
-        if (!more) break;
-        advance();
-        __syncthreads();          // everyone is done reading the staged chunk
-        write_lds();
-        __syncthreads();
-        more = dt <= pt;
+    };
+
+    // software pipeline: chunk kk is multiplied out of LDS while chunks kk+1 .. kk+PF are in
+    // flight in registers (set kk % PF holds chunk kk until it has been written to LDS)
+    int issued = 0;
+#pragma unroll
+    for (int s_ = 0; s_ < PF; ++s_)
+        if (issued < nch) {
+            issue(hreg[s_], wreg[s_]);
+            advance();
+            ++issued;
+        }
+    write_lds(hreg[0], wreg[0]);
+    __syncthreads();
+    for (int k = 0; k < nch; k += PF) {
+#pragma unroll
+        for (int par = 0; par < PF; ++par) {
+            const int kk = k + par;
+            if (kk < nch) {
+                if (issued < nch) {       // set `par` went to LDS already: refill it
+                    issue(hreg[par], wreg[par]);
+                    advance();
+                    ++issued;
+                }
+                compute();
+                if (kk + 1 < nch) {
+                    __syncthreads();      // everyone is done reading the staged chunk
+                    write_lds(hreg[(par + 1) % PF], wreg[(par + 1) % PF]);
+                    __syncthreads();
+                }
+            }
+        }
     }
 
-    const int h = h0 + wave, w = w0 + lr;
-    if (h >= a.H) return;
-    const long p = ((long)t * a.H + h) * a.W + w;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < RPW; ++j) {
+        const int h = h0 + wave * RPW + j, w = w0 + lr;
+        if (h >= a.H) continue;
+        const long p = ((long)t * a.H + h) * a.W + w;
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-            store_quad<E>(a, p, co0 + i * 32 + 8 * g + 4 * lh, acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2],
-                          acc[i][4 * g + 3]);
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                store_quad<E>(a, p, co0 + i * 32 + 8 * g + 4 * lh, acc[j][i][4 * g], acc[j][i][4 * g + 1],
+                              acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]);
+    }
 }
 
-template <typename E, int TH>
+template <typename E, int TH, int RPW, int PF>
 int launch_halo(const ConvArgs& a0, hipStream_t s) {
     ConvArgs a = a0;
     a.nCoTiles = cdiv(a.Cout, 64);
     const int grid = a.T * cdiv(a.H, TH) * (a.W / 32) * a.nCoTiles;
     const size_t lds = (size_t)(TH + 2) * 34 * 80 + 64 * 9 * 80;
-    hipLaunchKernelGGL((conv3x3_halo_kernel<E, TH>), dim3(grid), dim3(64 * TH), lds, s, a);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<E, TH, RPW, PF>), dim3(grid), dim3(64 * TH / RPW), lds, s, a);
     FLAIR_LAUNCH_CHECK();
     return FLAIR_OK;
 }
@@ -535,8 +569,8 @@ int choose_split(const ConvArgs& a, int variant) {
 int choose_variant(const ConvArgs& a) {
     if (a.KH == 3 && a.KW == 3 && a.W % 32 == 0 && a.H >= 2) {
         const long per = (long)a.T * (a.W / 32) * cdiv(a.Cout, 64);
-        if (per * cdiv(a.H, 8) >= 512) return 3;
-        if (per * cdiv(a.H, 4) >= 512) return 4;
+        if (per * cdiv(a.H, 8) >= 256) return 3;
+        if (per * cdiv(a.H, 4) >= 256) return 4;
         return 5;
     }
     const long tiles128 = (long)cdiv(a.P, 128) * cdiv(a.Cout, 128);
@@ -555,9 +589,9 @@ int dispatch(const ConvArgs& a0, hipStream_t s) {
         case 0: return launch<E, 128, 128, 2, 2>(a, s);
         case 1: return launch<E, 64, 128, 1, 4>(a, s);
         case 2: return launch<E, 64, 64, 2, 2>(a, s);
-        case 3: return launch_halo<E, 8>(a, s);
-        case 4: return launch_halo<E, 4>(a, s);
-        default: return launch_halo<E, 2>(a, s);
+        case 3: return launch_halo<E, 8, 1, 2>(a, s);
+        case 4: return launch_halo<E, 4, 1, 2>(a, s);
+        default: return launch_halo<E, 2, 1, 1>(a, s);
     }
 }
 
