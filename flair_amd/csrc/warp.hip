@@ -89,6 +89,84 @@ __global__ void flow_compose_kernel(const float* f1, const float* f2, int F, int
     }
 }
 
+
+// ---- BasicVSR++ alignment inputs of one propagation step in ONE launch (unet_new.py:704-722):
+//   cond_n1 = warp(prop, flow_n1);  flow_n2 = flow_n1 + warp(flow_prev, flow_n1);
+//   cond_n2 = warp(feat_n2, flow_n2);  flowpad[p][0..3] = (flow_n1, flow_n2) cast to E
+// One thread per (pixel, 16-byte channel chunk); the flow composition is recomputed per chunk
+// (2 channels, cheap) instead of being a launch of its own.
+__device__ __forceinline__ void bil_setup(float px, float py, int W, int H, int (&xy)[2], float (&wgt)[4]) {
+    const float ix = gs_coord(px, W), iy = gs_coord(py, H);
+    const float fx = floorf(ix), fy = floorf(iy);
+    xy[0] = (int)fminf(fmaxf(fx, -2.f), (float)W);
+    xy[1] = (int)fminf(fmaxf(fy, -2.f), (float)H);
+    const float ax = ix - fx, ay = iy - fy;
+    wgt[0] = (1.f - ax) * (1.f - ay); wgt[1] = ax * (1.f - ay); wgt[2] = (1.f - ax) * ay; wgt[3] = ax * ay;
+}
+
+template <typename E>
+__global__ void vsrpp_prep_kernel(const E* prop, int propLd, const E* feat2, int feat2Ld, const float* flow1,
+                                  const float* flowPrev, int H, int W, int C, E* cond1, int cond1Ld, E* cond2,
+                                  int cond2Ld, float* flow2Out, E* flowpad, int padLd) {
+    constexpr int VEC = ET<E>::VEC;
+    const int cv = C / VEC;
+    const long total = (long)H * W * cv;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % cv) * VEC;
+        const long p = i / cv;
+        const int w = (int)(p % W), h = (int)(p / W);
+        const float2 f1 = *reinterpret_cast<const float2*>(flow1 + p * 2);
+        int xy[2];
+        float wg[4];
+        bil_setup((float)w + f1.x, (float)h + f1.y, W, H, xy, wg);
+        float acc[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+        float2 f2 = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int xx = xy[0] + (q & 1), yy = xy[1] + (q >> 1);
+            if ((unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H) {
+                float v[VEC];
+                Vec16<E>::load(prop + ((long)yy * W + xx) * propLd + c0, v);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[k] = fmaf(wg[q], v[k], acc[k]);
+                if (flowPrev) {
+                    const float2 fp = *reinterpret_cast<const float2*>(flowPrev + ((long)yy * W + xx) * 2);
+                    f2.x = fmaf(wg[q], fp.x, f2.x);
+                    f2.y = fmaf(wg[q], fp.y, f2.y);
+                }
+            }
+        }
+        Vec16<E>::store(cond1 + p * cond1Ld + c0, acc);
+        if (flowPrev) {
+            f2.x += f1.x;
+            f2.y += f1.y;
+            bil_setup((float)w + f2.x, (float)h + f2.y, W, H, xy, wg);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int xx = xy[0] + (q & 1), yy = xy[1] + (q >> 1);
+                if ((unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H) {
+                    float v[VEC];
+                    Vec16<E>::load(feat2 + ((long)yy * W + xx) * feat2Ld + c0, v);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[k] = fmaf(wg[q], v[k], acc[k]);
+                }
+            }
+            Vec16<E>::store(cond2 + p * cond2Ld + c0, acc);
+        }
+        if (c0 == 0) {
+            if (flowPrev) *reinterpret_cast<float2*>(flow2Out + p * 2) = f2;
+            ET<E>::st(flowpad + p * padLd + 0, f1.x);
+            ET<E>::st(flowpad + p * padLd + 1, f1.y);
+            ET<E>::st(flowpad + p * padLd + 2, f2.x);
+            ET<E>::st(flowpad + p * padLd + 3, f2.y);
+        }
+    }
+}
+
 // ---- generic scalar-channel resize (few channels: images and flows) ------------------
 __device__ __forceinline__ float cubic1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
 __device__ __forceinline__ float cubic2(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
@@ -211,6 +289,30 @@ extern "C" int flair_resize_nhwc(const void* x, int dtype, int x_ld, int F, int 
                            Hi, Wi, C, mode, Ho, Wo, (float*)y, y_ld, scale_c0, scale_c1);
     else
         FLAIR_CHECK(false, "flair_resize_nhwc: bad dtype");
+    FLAIR_LAUNCH_CHECK();
+    return FLAIR_OK;
+}
+
+extern "C" int flair_vsrpp_prep(const void* prop, int prop_ld, const void* feat2, int feat2_ld, const float* flow1,
+                                const float* flow_prev, int dtype, int H, int W, int C, void* cond1, int cond1_ld,
+                                void* cond2, int cond2_ld, float* flow2_out, void* flowpad, int pad_ld,
+                                hipStream_t stream) {
+    FLAIR_CHECK(prop && flow1 && cond1 && flowpad && H > 0 && W > 0 && C > 0 && pad_ld >= 4,
+                "flair_vsrpp_prep: bad argument");
+    FLAIR_CHECK(!flow_prev || (feat2 && cond2 && flow2_out), "flair_vsrpp_prep: second-order inputs incomplete");
+    if (dtype == FLAIR_BF16) {
+        FLAIR_CHECK(C % 8 == 0, "flair_vsrpp_prep: C %% 8");
+        hipLaunchKernelGGL(vsrpp_prep_kernel<bf16_t>, dim3(grid_for((long)H * W * (C / 8))), dim3(256), 0, stream,
+                           (const bf16_t*)prop, prop_ld, (const bf16_t*)feat2, feat2_ld, flow1, flow_prev, H, W, C,
+                           (bf16_t*)cond1, cond1_ld, (bf16_t*)cond2, cond2_ld, flow2_out, (bf16_t*)flowpad, pad_ld);
+    } else if (dtype == FLAIR_F32) {
+        FLAIR_CHECK(C % 4 == 0, "flair_vsrpp_prep: C %% 4");
+        hipLaunchKernelGGL(vsrpp_prep_kernel<float>, dim3(grid_for((long)H * W * (C / 4))), dim3(256), 0, stream,
+                           (const float*)prop, prop_ld, (const float*)feat2, feat2_ld, flow1, flow_prev, H, W, C,
+                           (float*)cond1, cond1_ld, (float*)cond2, cond2_ld, flow2_out, (float*)flowpad, pad_ld);
+    } else {
+        FLAIR_CHECK(false, "flair_vsrpp_prep: bad dtype");
+    }
     FLAIR_LAUNCH_CHECK();
     return FLAIR_OK;
 }

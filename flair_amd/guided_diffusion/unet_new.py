@@ -371,15 +371,16 @@ class BasicVSRPP(nn.Module):
             cur = hidden[idx:idx + 1]
             if i > 0:
                 flow_n1 = flows[flow_idx[i]:flow_idx[i] + 1]
-                cond_n1 = ops.flow_warp(prop, flow_n1)
+                cond_n1 = torch.empty_like(zero_c)
                 if i > 1:
                     feat_n2 = prev2
-                    flow_n2 = ops.flow_compose(flow_n1, flows[flow_idx[i - 1]:flow_idx[i - 1] + 1])
-                    cond_n2 = ops.flow_warp(feat_n2, flow_n2)
-                    ops.cast_channels(flow_n2, flowpad, 2)
+                    cond_n2 = torch.empty_like(zero_c)
+                    flow_n2 = torch.empty_like(flow_n1)
+                    ops.vsrpp_prep(prop, feat_n2, flow_n1, flows[flow_idx[i - 1]:flow_idx[i - 1] + 1],
+                                   cond_n1, cond_n2, flow_n2, flowpad)
                 else:
                     feat_n2, flow_n2, cond_n2 = zero_c, None, zero_c
-                ops.cast_channels(flow_n1, flowpad, 0)
+                    ops.vsrpp_prep(prop, None, flow_n1, None, cond_n1, None, None, flowpad)
                 o = ops.conv([cond_n1, cur, cond_n2, flowpad], pk_a["w0"], pk_a["b0"], c, k3, act=A.ACT_LRELU01)
                 o = ops.conv(o, pk_a["w2"], pk_a["b2"], c, k3, act=A.ACT_LRELU01)
                 o = ops.conv(o, pk_a["w4"], pk_a["b4"], c, k3, act=A.ACT_LRELU01)
@@ -603,6 +604,16 @@ class UNetModel(nn.Module):
                                  zero_module(LazyReshaper2D(conv_nd(dims, input_ch, out_channels, 3, padding=1))))
         self._packed_key = None
         self._flow_cache = {}
+        self._graphs = {}
+        self.use_hip_graph = False
+
+    def enable_hip_graph(self, flag=True):
+        """Replay one captured hipGraph per (clip shape, dtype) instead of ~7000 launches per
+        forward.  Inputs are copied into static buffers; the returned tensor is overwritten by
+        the next call (the sampler consumes it immediately)."""
+        self.use_hip_graph = bool(flag)
+        self._graphs = {}
+        return self
 
     # ---- dtype management (reference names) ------------------------------------------
     def convert_to_fp16(self):
@@ -610,14 +621,17 @@ class UNetModel(nn.Module):
         accumulate; GroupNorm statistics, embeddings, flows and SPyNet stay f32)."""
         self.dtype = torch.bfloat16
         self._packed_key = None
+        self._graphs = {}
 
     def convert_to_fp32(self):
         self.dtype = torch.float32
         self._packed_key = None
+        self._graphs = {}
 
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)
         self._packed_key = None
+        self._graphs = {}
         return out
 
     def reset_flow_cache(self):
@@ -727,10 +741,47 @@ class UNetModel(nn.Module):
             vw = vsrpp_weights
             if isinstance(vw, torch.Tensor):
                 vw = vw[b]
-            outs.append(self._forward_clip(x[b * T:(b + 1) * T].float().contiguous(),
-                                           timesteps[b * T:(b + 1) * T], low_res_input[b].float(),
-                                           rnn_input[b].float(), enable_cross_frames, vw))
+            fn = self._forward_clip_graphed if (self.use_hip_graph and not isinstance(vw, torch.Tensor)
+                                                and getattr(self, "_trace", None) is None) else self._forward_clip
+            outs.append(fn(x[b * T:(b + 1) * T].float().contiguous(), timesteps[b * T:(b + 1) * T],
+                           low_res_input[b].float(), rnn_input[b].float(), enable_cross_frames, vw))
         return outs[0] if B == 1 else torch.cat(outs, dim=0)
+
+    def _forward_clip_graphed(self, x, t, low_res, rnn, enable_cross_frames, vsrpp_weights):
+        key = (tuple(x.shape), self.dtype, bool(enable_cross_frames), vsrpp_weights, x.device)
+        ent = self._graphs.get(key)
+        src = (rnn.data_ptr(), rnn._version, low_res.data_ptr(), low_res._version)
+        if ent is None:
+            st = dict(x=x.clone(), t=t.clone(), lr=low_res.clone(), rnn=rnn.clone())
+            self._flows_for(st["rnn"])                       # SPyNet runs eagerly, before capture
+            cur = torch.cuda.current_stream()
+            side = torch.cuda.Stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):                    # warm-up (allocator, workspaces)
+                self._forward_clip(st["x"], st["t"], st["lr"], st["rnn"], enable_cross_frames, vsrpp_weights)
+            cur.wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self._forward_clip(st["x"], st["t"], st["lr"], st["rnn"], enable_cross_frames,
+                                         vsrpp_weights)
+            ent = dict(graph=graph, st=st, out=out, src=src)
+            self._graphs[key] = ent
+        st = ent["st"]
+        if ent["src"] != src:                                # a new clip: refresh conditioning + flows
+            old = self._flows_for(st["rnn"])
+            st["lr"].copy_(low_res)
+            st["rnn"].copy_(rnn)
+            new = self._flows_for(st["rnn"])                 # version bumped -> recomputed
+            for r in old:                                    # the graph holds the old flow buffers
+                for o, n in zip(old[r], new[r]):
+                    o.copy_(n)
+            self._flow_cache[(st["rnn"].data_ptr(), st["rnn"]._version, tuple(st["rnn"].shape))] = (old, st["rnn"])
+            ent["src"] = src
+        st["x"].copy_(x)
+        st["t"].copy_(t)
+        ent["graph"].replay()
+        return ent["out"]
 
     def _forward_clip(self, x, t, low_res, rnn, enable_cross_frames, vsrpp_weights):
         T, _, H, W = x.shape

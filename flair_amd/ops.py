@@ -485,3 +485,15 @@ def gather_mac(x, outer, lin, inner, fov, w):
     check(lib().flair_gather_mac_f32(ptr(x), ctypes.c_long(outer), lin, ctypes.c_long(inner), ptr(fov.contiguous()),
                                      ptr(w.contiguous()), taps, lout, ptr(out), stream()), "flair_gather_mac_f32")
     return out
+
+
+def vsrpp_prep(prop, feat2, flow1, flow_prev, cond1, cond2, flow2_out, flowpad):
+    """Fused alignment inputs of one BasicVSR++ step (see flair_vsrpp_prep).  One frame:
+    prop/feat2/cond*: (1,H,W,c) clip tensors; flows: (1,H,W,2) f32; flowpad: (1,H,W,>=4)."""
+    _, H, W, C = prop.shape
+    second = flow_prev is not None
+    check(lib().flair_vsrpp_prep(ptr(prop), _ld(prop), ptr(feat2 if second else None),
+                                 _ld(feat2) if second else 0, ptr(_f32(flow1)), ptr(_f32(flow_prev)),
+                                 dtype_code(prop), H, W, C, ptr(cond1), _ld(cond1), ptr(cond2 if second else None),
+                                 _ld(cond2) if second else 0, ptr(flow2_out if second else None), ptr(flowpad),
+                                 _ld(flowpad), stream()), "flair_vsrpp_prep")

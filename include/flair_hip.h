@@ -226,6 +226,14 @@ int flair_flow_warp(const void* x, int dtype, int x_ld, const float* flow, int f
 /* out = f1 + warp(f2, f1) on flow fields (unet_new.py:716-718). */
 int flair_flow_compose(const float* f1, const float* f2, int F, int H, int W, float* out,
                        hipStream_t stream);
+/* One BasicVSR++ propagation step's alignment inputs in one launch (unet_new.py:704-722):
+ * cond1 = warp(prop, flow1); flow2 = flow1 + warp(flow_prev, flow1); cond2 = warp(feat2, flow2);
+ * flowpad[p][0..3] = (flow1, flow2) in the activation dtype.  flow_prev == NULL: first-order
+ * step (cond2 / flow2_out untouched, flowpad[2..3] = 0).  One frame: tensors are [H][W][*]. */
+int flair_vsrpp_prep(const void* prop, int prop_ld, const void* feat2, int feat2_ld,
+                     const float* flow1, const float* flow_prev, int dtype, int H, int W, int C,
+                     void* cond1, int cond1_ld, void* cond2, int cond2_ld, float* flow2_out,
+                     void* flowpad, int pad_ld, hipStream_t stream);
 /* mode 0/1: bilinear (align_corners False/True), 2: bicubic (A=-0.75), 3: 2x2 avg-pool,
  * 4: nearest;
  * channel 0 / 1 of the result are multiplied by scale_c0 / scale_c1 (flow rescaling). */

@@ -117,3 +117,32 @@ def test_jpeg_roundtrip_vs_oracle(dev, qf):
     # <=0.5% of pixels to sit in a flipped block.
     frac_bad = (diff > 1e-4).float().mean().item()
     assert frac_bad <= 5e-3, (frac_bad, diff.max().item())
+
+
+@pytest.mark.parametrize("f", [8, 16])
+def test_srconv_vs_oracle_and_golden(dev, f):
+    """SRConv A / A_pinv (two batched matmuls on the GPU) vs the oracle and the reference's vectors."""
+    import os
+    from flair_amd.guided_diffusion.restore_util import SRConv
+    from oracle import degrade as odeg
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "g6_degrade.npz")))
+    img = torch.from_numpy(g["img"])
+    taps = torch.from_numpy(odeg.bicubic_taps(f)).float()
+    sr = SRConv(taps / taps.sum(), 3, 64, dev, stride=f)
+    y = sr.A(img.reshape(2, -1).to(dev))
+    assert np.abs(y.cpu().numpy() - g[f"srconv{f}_A"]).max() <= 5e-5
+    back = sr.A_pinv(torch.from_numpy(g[f"srconv{f}_A"]).to(dev))
+    assert np.abs(back.cpu().numpy() - g[f"srconv{f}_pinv"]).max() <= 5e-4
+    # projection property: A A^+ A = A
+    assert (sr.A(sr.A_pinv(y)) - y).abs().max().item() <= 1e-3
+
+
+def test_resizer_vs_golden(dev):
+    import os
+    from flair_amd.guided_diffusion.resizer import Resizer
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "g6_degrade.npz")))
+    img, low = torch.from_numpy(g["img"]), torch.from_numpy(g["low"])
+    down = Resizer(img.shape, 1 / 8)(img.to(dev))
+    up = Resizer(low.shape, 8)(low.to(dev))
+    assert np.abs(down.cpu().numpy() - g["resizer_down8"]).max() <= 1e-5
+    assert np.abs(up.cpu().numpy() - g["resizer_up8"]).max() <= 1e-5

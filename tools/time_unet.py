@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--graph", action="store_true")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
@@ -43,6 +44,12 @@ def main():
     y = m(x, t, **kw)
     torch.cuda.synchronize()
     print(f"first forward (pack + spynet) {time.time()-t0:.2f}s  out {tuple(y.shape)} finite={torch.isfinite(y).all().item()}", flush=True)
+    if a.graph:
+        m.enable_hip_graph()
+        t0 = time.time()
+        y = m(x, t, **kw)
+        torch.cuda.synchronize()
+        print(f"graph capture {time.time()-t0:.2f}s", flush=True)
     for _ in range(a.iters):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.time()
