@@ -243,30 +243,40 @@ void conv3x3_halo_kernel(ConvArgs a) {
             for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
 
     auto compute = [&]() {
-        // ---- 9 taps x 2 k-steps out of LDS; the two weight fragments are reused by RPW rows
+        // ---- 9 taps x 2 k-steps out of LDS.  Fragments of tap t+1 are requested before the
+        // MFMAs of tap t are issued (two fragment sets), so LDS latency hides under the matrix pipe.
         const char* hb = sh + ((wave * RPW * HW_) + lr) * PITCH;
         const char* wb0 = sw + (lr * 9) * PITCH;
         const char* wb1 = sw + ((lr + 32) * 9) * PITCH;
+        uint4 fa0[2][2], fa1[2][2], fb[2][RPW][2];
+        auto load_tap = [&](int set, int tap9) {
+            const int kh = tap9 / 3, kw = tap9 % 3;
+            fa0[set][0] = *reinterpret_cast<const uint4*>(wb0 + tap9 * PITCH + 16 * Mma<E>::chunk(0, lh));
+            fa0[set][1] = *reinterpret_cast<const uint4*>(wb0 + tap9 * PITCH + 16 * Mma<E>::chunk(1, lh));
+            fa1[set][0] = *reinterpret_cast<const uint4*>(wb1 + tap9 * PITCH + 16 * Mma<E>::chunk(0, lh));
+            fa1[set][1] = *reinterpret_cast<const uint4*>(wb1 + tap9 * PITCH + 16 * Mma<E>::chunk(1, lh));
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int tap9 = kh * 3 + kw;
-                uint4 a0[2], a1[2];
-                a0[0] = *reinterpret_cast<const uint4*>(wb0 + tap9 * PITCH + 16 * Mma<E>::chunk(0, lh));
-                a0[1] = *reinterpret_cast<const uint4*>(wb0 + tap9 * PITCH + 16 * Mma<E>::chunk(1, lh));
-                a1[0] = *reinterpret_cast<const uint4*>(wb1 + tap9 * PITCH + 16 * Mma<E>::chunk(0, lh));
-                a1[1] = *reinterpret_cast<const uint4*>(wb1 + tap9 * PITCH + 16 * Mma<E>::chunk(1, lh));
-#pragma unroll
-                for (int j = 0; j < RPW; ++j) {
-                    const char* hp = hb + ((j + kh) * HW_ + kw) * PITCH;
-                    uint4 bf[2];
-                    bf[0] = *reinterpret_cast<const uint4*>(hp + 16 * Mma<E>::chunk(0, lh));
-                    bf[1] = *reinterpret_cast<const uint4*>(hp + 16 * Mma<E>::chunk(1, lh));
-                    Mma<E>::run(a0, bf, acc[j][0]);
-                    Mma<E>::run(a1, bf, acc[j][1]);
-                }
+            for (int j = 0; j < RPW; ++j) {
+                const char* hp = hb + ((j + kh) * HW_ + kw) * PITCH;
+                fb[set][j][0] = *reinterpret_cast<const uint4*>(hp + 16 * Mma<E>::chunk(0, lh));
+                fb[set][j][1] = *reinterpret_cast<const uint4*>(hp + 16 * Mma<E>::chunk(1, lh));
             }
+        };
+        load_tap(0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4 + 2 * RPW, 0);
+#pragma unroll
+        for (int tap9 = 0; tap9 < 9; ++tap9) {
+            const int set = tap9 & 1;
+            if (tap9 < 8) load_tap(set ^ 1, tap9 + 1);
+#pragma unroll
+            for (int j = 0; j < RPW; ++j) {
+                Mma<E>::run(fa0[set], fb[set][j], acc[j][0]);
+                Mma<E>::run(fa1[set], fb[set][j], acc[j][1]);
+            }
+            // pin the interleave: next tap's LDS reads are issued ahead of this tap's MFMAs
+            if (tap9 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 4 + 2 * RPW, 0);
+            __builtin_amdgcn_sched_group_barrier(0x8, (sizeof(E) == 2 ? 4 : 16) * RPW, 0);
+        }
     };
 
     // software pipeline: chunk kk is multiplied out of LDS while chunks kk+1 .. kk+PF are in
@@ -589,8 +599,8 @@ int dispatch(const ConvArgs& a0, hipStream_t s) {
         case 0: return launch<E, 128, 128, 2, 2>(a, s);
         case 1: return launch<E, 64, 128, 1, 4>(a, s);
         case 2: return launch<E, 64, 64, 2, 2>(a, s);
-        case 3: return launch_halo<E, 8, 1, 2>(a, s);
-        case 4: return launch_halo<E, 4, 1, 2>(a, s);
+        case 3: return launch_halo<E, 8, 1, 1>(a, s);
+        case 4: return launch_halo<E, 4, 1, 1>(a, s);
         default: return launch_halo<E, 2, 1, 1>(a, s);
     }
 }
