@@ -30,7 +30,7 @@ class ConvParams(ctypes.Structure):
                 ("KW", ctypes.c_int), ("Cout", ctypes.c_int), ("nseg", ctypes.c_int),
                 ("seg_c", ctypes.c_int * 4), ("seg_ld", ctypes.c_int * 4),
                 ("y_ld", ctypes.c_int), ("res_ld", ctypes.c_int * 2), ("act", ctypes.c_int),
-                ("out_scale", ctypes.c_float)]
+                ("out_scale", ctypes.c_float), ("frame_bias_ld", ctypes.c_int), ("stride", ctypes.c_int)]
 
 
 _lib = None

@@ -47,6 +47,10 @@ struct ConvArgs {
     unsigned wBytes;
     float* part;           // split-K: f32 partial sums [splitK][P][Cout] (null when splitK == 1)
     int splitK;
+    const float* fbias;    // optional per-(frame, channel) bias [T][fbiasLd] (emb added to h)
+    int fbiasLd;
+    int stride;            // spatial stride (1 or 2; im2col path only)
+    int Hin, Win;          // input frame size (== H, W when stride == 1); H, W, P describe the OUTPUT
 };
 
 template <typename E> struct Mma;
@@ -90,6 +94,10 @@ __device__ __forceinline__ void store_quad(const ConvArgs& a, long p, int co, fl
     if (a.bias) {
         const float4 b = *reinterpret_cast<const float4*>(a.bias + co);
         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+    if (a.fbias) {
+        const float* fb = a.fbias + (p / ((long)a.H * a.W)) * a.fbiasLd + co;
+        v[0] += fb[0]; v[1] += fb[1]; v[2] += fb[2]; v[3] += fb[3];
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], a.act);
@@ -402,10 +410,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         const int coff = cb * BKE + chunk * VEC;
 #pragma unroll
         for (int i = 0; i < XR; ++i) {
-            const int t2 = xt[i] + dt, h2 = xh[i] + dh, w2 = xw[i] + dw;
-            const bool ok = xvalid[i] && (unsigned)t2 < (unsigned)a.T && (unsigned)h2 < (unsigned)a.H &&
-                            (unsigned)w2 < (unsigned)a.W;
-            const unsigned off = ok ? (unsigned)(((t2 * a.H + h2) * a.W + w2) * ld + coff) * ESZ : FLAIR_OOB;
+            const int t2 = xt[i] + dt, h2 = xh[i] * a.stride + dh, w2 = xw[i] * a.stride + dw;
+            const bool ok = xvalid[i] && (unsigned)t2 < (unsigned)a.T && (unsigned)h2 < (unsigned)a.Hin &&
+                            (unsigned)w2 < (unsigned)a.Win;
+            const unsigned off = ok ? (unsigned)(((t2 * a.Hin + h2) * a.Win + w2) * ld + coff) * ESZ : FLAIR_OOB;
             xreg[i] = buf_load16(xr, off);
         }
         const unsigned kofs = (unsigned)(tap * a.CinTot + segOff + coff) * ESZ;
@@ -577,7 +585,7 @@ int choose_split(const ConvArgs& a, int variant) {
 // W a multiple of 32); 0..2: im2col tiles 128 couts x 128 pixels, 64 x 128, 64 x 64.
 // Either way keep >= ~2 workgroups per CU when the problem allows it.
 int choose_variant(const ConvArgs& a) {
-    if (a.KH == 3 && a.KW == 3 && a.W % 32 == 0 && a.H >= 2) {
+    if (a.stride == 1 && a.KH == 3 && a.KW == 3 && a.W % 32 == 0 && a.H >= 2) {
         const long per = (long)a.T * (a.W / 32) * cdiv(a.Cout, 64);
         if (per * cdiv(a.H, 8) >= 256) return 3;
         if (per * cdiv(a.H, 4) >= 256) return 4;
@@ -610,8 +618,12 @@ int dispatch(const ConvArgs& a0, hipStream_t s) {
 extern "C" int flair_conv_variant(const flair_conv_params* p);
 
 static void fill_geometry(ConvArgs& a, const flair_conv_params* p) {
-    a.T = p->T; a.H = p->H; a.W = p->W; a.KT = p->KT; a.KH = p->KH; a.KW = p->KW; a.Cout = p->Cout;
-    a.P = (long)p->T * p->H * p->W;
+    a.stride = p->stride > 1 ? p->stride : 1;
+    a.Hin = p->H; a.Win = p->W;
+    a.T = p->T; a.KT = p->KT; a.KH = p->KH; a.KW = p->KW; a.Cout = p->Cout;
+    a.H = (p->H + a.stride - 1) / a.stride;       // "same"-style padding K/2: out = ceil(in / stride)
+    a.W = (p->W + a.stride - 1) / a.stride;
+    a.P = (long)p->T * a.H * a.W;
     a.CinTot = 0;
     for (int i = 0; i < p->nseg && i < 4; ++i) a.CinTot += p->seg_c[i];
     const int esz = p->dtype == FLAIR_BF16 ? 2 : 4;
@@ -627,8 +639,8 @@ extern "C" size_t flair_conv_workspace_bytes(const flair_conv_params* p) {
 }
 
 extern "C" int flair_conv_nhwc(const flair_conv_params* p, const void* const* x, const void* w,
-                               const float* bias, const void* res0, const void* res1, void* y,
-                               void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                               const float* bias, const float* frame_bias, const void* res0, const void* res1,
+                               void* y, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     FLAIR_CHECK(p && x && w && y, "flair_conv_nhwc: null argument");
     FLAIR_CHECK(p->dtype == FLAIR_F32 || p->dtype == FLAIR_BF16, "flair_conv_nhwc: bad dtype %d", p->dtype);
     FLAIR_CHECK(p->nseg >= 1 && p->nseg <= 4, "flair_conv_nhwc: nseg %d not in 1..4", p->nseg);
@@ -651,7 +663,7 @@ extern "C" int flair_conv_nhwc(const flair_conv_params* p, const void* const* x,
         a.segLd[i] = p->seg_ld[i];
         a.CinTot += p->seg_c[i];
         const unsigned long long bytes =
-            (((unsigned long long)p->T * p->H * p->W - 1) * p->seg_ld[i] + p->seg_c[i]) * esz;
+            (((unsigned long long)p->T * p->H * p->W - 1) * p->seg_ld[i] + p->seg_c[i]) * esz;   // input pixels
         FLAIR_CHECK(bytes < 0x80000000ull, "flair_conv_nhwc: segment %d spans %llu bytes (limit 2 GiB)", i, bytes);
         a.segBytes[i] = (unsigned)bytes;
     }
@@ -667,18 +679,24 @@ extern "C" int flair_conv_nhwc(const flair_conv_params* p, const void* const* x,
     a.nseg = p->nseg;
     a.w = w;
     a.bias = bias;
+    a.fbias = frame_bias;
+    a.fbiasLd = p->frame_bias_ld;
+    FLAIR_CHECK(!frame_bias || p->frame_bias_ld >= p->Cout, "flair_conv_nhwc: frame_bias_ld");
     a.res0 = res0;
     a.res1 = res1;
     a.res0Ld = p->res_ld[0];
     a.res1Ld = p->res_ld[1];
     a.y = y;
     a.yLd = p->y_ld;
-    a.T = p->T; a.H = p->H; a.W = p->W;
-    a.KT = p->KT; a.KH = p->KH; a.KW = p->KW;
-    a.Cout = p->Cout;
     a.act = p->act;
     a.outScale = p->out_scale;
-    a.P = (long)p->T * p->H * p->W;
+    {
+        ConvArgs g{};
+        fill_geometry(g, p);
+        a.stride = g.stride; a.Hin = g.Hin; a.Win = g.Win; a.T = g.T; a.H = g.H; a.W = g.W; a.P = g.P;
+        a.KT = g.KT; a.KH = g.KH; a.KW = g.KW; a.Cout = g.Cout;
+    }
+    FLAIR_CHECK(a.stride == 1 || a.stride == 2, "flair_conv_nhwc: stride %d unsupported", p->stride);
     a.part = nullptr;
     a.splitK = 1;
     if (workspace && workspace_bytes >= flair_conv_workspace_bytes(p) && flair_conv_workspace_bytes(p) > 0) {

@@ -28,7 +28,8 @@ __global__ void nhwc_to_nchw_kernel(const E* src, int ld, int coff, int N, int C
 }
 
 // ---- sinusoidal embedding: out[n] = [cos(t*f_i) | sin(t*f_i)], f_i = P^(-i/half) ---
-__global__ void timestep_embedding_kernel(const float* t, int N, int dim, float maxPeriod, float* out) {
+__global__ void timestep_embedding_kernel(const float* t, int N, int dim, float maxPeriod, int sinFirst,
+                                          float* out) {
     const int half = dim / 2;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N * half) return;
@@ -36,8 +37,8 @@ __global__ void timestep_embedding_kernel(const float* t, int N, int dim, float 
     // same operation order as the reference: exp(-log(P) * k / half) in f32
     const float freq = expf(-logf(maxPeriod) * (float)k / (float)half);
     const float arg = t[n] * freq;
-    out[(long)n * dim + k] = cosf(arg);
-    out[(long)n * dim + half + k] = sinf(arg);
+    out[(long)n * dim + (sinFirst ? half : 0) + k] = cosf(arg);
+    out[(long)n * dim + (sinFirst ? 0 : half) + k] = sinf(arg);
     if ((dim & 1) && k == 0) out[(long)n * dim + dim - 1] = 0.f;
 }
 
@@ -171,6 +172,29 @@ __global__ void add_frame_bias_kernel(E* x, int ld, int C, int F, long HW, const
     }
 }
 
+// y = x + sigmoid(g[f][c]) * (m - x)
+template <typename E>
+__global__ void gated_blend_kernel(const E* x, int xLd, const E* m, int mLd, const float* gate, int gLd, int C, int F,
+                                   long HW, E* y, int yLd) {
+    constexpr int VEC = ET<E>::VEC;
+    const int cv = C / VEC;
+    const long total = (long)F * HW * cv;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % cv) * VEC;
+        const long p = i / cv;
+        const long f = p / HW;
+        float a[VEC], b[VEC];
+        Vec16<E>::load(x + p * xLd + c0, a);
+        Vec16<E>::load(m + p * mLd + c0, b);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const float s = 1.f / (1.f + __expf(-gate[f * gLd + c0 + k]));
+            a[k] = (1.f - s) * a[k] + s * b[k];
+        }
+        Vec16<E>::store(y + p * yLd + c0, a);
+    }
+}
+
 // dst[p][coff + c] = (E) src[p][c]  for c < C   (f32 flow fields into a conv input segment)
 template <typename E>
 __global__ void cast_channels_kernel(const float* src, int sLd, int C, long P, E* dst, int dLd, int coff) {
@@ -225,12 +249,12 @@ extern "C" int flair_nhwc_to_nchw_f32(const void* src, int dtype, int src_ld, in
     return FLAIR_OK;
 }
 
-extern "C" int flair_timestep_embedding(const float* t, int N, int dim, float max_period, float* out,
-                                        hipStream_t stream) {
+extern "C" int flair_timestep_embedding(const float* t, int N, int dim, float max_period, int sin_first,
+                                        float* out, hipStream_t stream) {
     FLAIR_CHECK(t && out && N > 0 && dim >= 2, "flair_timestep_embedding: bad argument");
     const int n = N * (dim / 2);
     hipLaunchKernelGGL(timestep_embedding_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, t, N, dim, max_period,
-                       out);
+                       sin_first, out);
     FLAIR_LAUNCH_CHECK();
     return FLAIR_OK;
 }
@@ -370,6 +394,24 @@ extern "C" int flair_learned_range_variance(const float* model_out, int N, int C
     const long HW = (long)H * W;
     hipLaunchKernelGGL(learned_range_kernel, dim3(grid_for((long)N * C * HW)), dim3(256), 0, stream, model_out, N, C,
                        HW, min_log, max_log, variance, log_variance);
+    FLAIR_LAUNCH_CHECK();
+    return FLAIR_OK;
+}
+
+extern "C" int flair_gated_blend(const void* x, int x_ld, const void* m, int m_ld, const float* gate, int gate_ld,
+                                 int dtype, int C, int F, long HW, void* y, int y_ld, hipStream_t stream) {
+    FLAIR_CHECK(x && m && gate && y && C > 0 && F > 0 && HW > 0 && gate_ld >= C, "flair_gated_blend: bad argument");
+    if (dtype == FLAIR_BF16) {
+        FLAIR_CHECK(C % 8 == 0, "flair_gated_blend: C %% 8");
+        hipLaunchKernelGGL(gated_blend_kernel<bf16_t>, dim3(grid_for(F * HW * (C / 8))), dim3(256), 0, stream,
+                           (const bf16_t*)x, x_ld, (const bf16_t*)m, m_ld, gate, gate_ld, C, F, HW, (bf16_t*)y, y_ld);
+    } else if (dtype == FLAIR_F32) {
+        FLAIR_CHECK(C % 4 == 0, "flair_gated_blend: C %% 4");
+        hipLaunchKernelGGL(gated_blend_kernel<float>, dim3(grid_for(F * HW * (C / 4))), dim3(256), 0, stream,
+                           (const float*)x, x_ld, (const float*)m, m_ld, gate, gate_ld, C, F, HW, (float*)y, y_ld);
+    } else {
+        FLAIR_CHECK(false, "flair_gated_blend: bad dtype");
+    }
     FLAIR_LAUNCH_CHECK();
     return FLAIR_OK;
 }

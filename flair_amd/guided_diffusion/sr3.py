@@ -1,0 +1,504 @@
+"""SR3-style video UNet of the bicubic x8 / x16 tasks, executed by the gfx950 kernels.
+
+Python surface of the reference's ``guided_diffusion/sr3.py`` (``UNet`` with the same
+constructor / ``forward`` arguments and state-dict names, sr3.py:317-525) including the blocks
+it borrows from ``guided_diffusion/unet.py`` (ResBlock with a (3,1,1) kernel, 7-frame
+TemporalAttention, BasicVSRPP that computes its own flows).  Same execution model as
+``unet_new.UNetModel``: NHWC clip tensors, every layer a few calls into libflair_hip.so.
+
+MI355X-specific restructuring:
+  * every noise-embedding linear of the network (FeatureWiseAffine, the gates of
+    TemporalWrapper2, ResBlock.emb_layers) is evaluated in two launches per step and the
+    per-frame terms are folded into the convolution epilogue (``frame_bias``);
+  * each BasicVSRPP instance of the reference resizes the low-quality clip and runs SPyNet
+    itself on every step (unet.py:546-564): flows are a function of (clip, resolution) only
+    and are computed once per clip and shared by all instances of that resolution;
+  * Downsample = 3x3 stride-2 convolution on the im2col MFMA path.
+Shipped configuration only: spatial_attn=False, with_noise_level_emb=True.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .nn_new import linear, zero_module
+from .unet_new import (A, BasicVSRPP, Ctx, PlaceHolder, SPyNet, TemporalAttention, _dev, _pack, normalization)
+
+LazyReshaper2D = LazyReshaper3D = PlaceHolder
+
+
+# ------------------------------------------------------------------------ antialiased resize
+def aa_bilinear_table(n_in, n_out):
+    """Index/weight table of F.interpolate(mode='bilinear', antialias=True, align_corners=False)
+    along one axis (triangle filter stretched by the scale when down-sampling), as
+    (taps, n_out) arrays for ``flair_gather_mac_f32``."""
+    scale = n_in / n_out
+    support = scale if scale >= 1.0 else 1.0
+    inv = 1.0 / scale if scale >= 1.0 else 1.0
+    rows_i, rows_w = [], []
+    for i in range(n_out):
+        center = scale * (i + 0.5)
+        lo = max(int(center - support + 0.5), 0)
+        hi = min(int(center + support + 0.5), n_in)
+        js = np.arange(lo, hi)
+        w = np.clip(1.0 - np.abs((js - center + 0.5) * inv), 0.0, None).astype(np.float32)
+        w = w / w.sum()
+        rows_i.append(js)
+        rows_w.append(w)
+    taps = max(len(r) for r in rows_i)
+    idx = np.zeros((taps, n_out), dtype=np.int32)
+    wt = np.zeros((taps, n_out), dtype=np.float32)
+    for i, (js, w) in enumerate(zip(rows_i, rows_w)):
+        idx[:len(js), i] = js
+        wt[:len(js), i] = w
+        idx[len(js):, i] = js[-1]
+    return idx, wt
+
+
+def aa_resize(x, size):
+    """(N,C,H,W) f32 device tensor -> (N,C,size,size) with antialiased bilinear filtering."""
+    N, C, H, W = x.shape
+    dev = x.device
+    out = x.float().contiguous()
+    for dim, n_in in ((2, H), (3, W)):
+        idx, wt = aa_bilinear_table(n_in, size)
+        shape = list(out.shape)
+        outer = int(np.prod(shape[:dim]))
+        inner = int(np.prod(shape[dim + 1:])) if dim + 1 < 4 else 1
+        out = ops.gather_mac(out, outer, n_in, inner, torch.from_numpy(idx).to(dev), torch.from_numpy(wt).to(dev))
+        shape[dim] = size
+        out = out.reshape(shape)
+    return out
+
+
+# ------------------------------------------------------------------------------- containers
+class PositionalEncoding(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.dim = dim
+
+
+class Swish(nn.Module):
+    pass
+
+
+class FeatureWiseAffine(nn.Module):
+    def __init__(self, in_channels, out_channels, use_affine_level=False):
+        super().__init__()
+        if use_affine_level:
+            raise NotImplementedError("flair_amd: use_affine_level is not used by FLAIR")
+        self.noise_func = nn.Sequential(nn.Linear(in_channels, out_channels))
+
+
+class Block(nn.Module):
+    """sr3.py:113-126."""
+
+    def __init__(self, dim, dim_out, groups=32, dropout=0):
+        super().__init__()
+        self.block = nn.Sequential(LazyReshaper3D(nn.GroupNorm(groups, dim)), Swish(), nn.Identity(),
+                                   LazyReshaper2D(nn.Conv2d(dim, dim_out, 3, padding=1)))
+        self.groups = groups
+
+
+class ResnetBlock(nn.Module):
+    """sr3.py:129-161."""
+
+    def __init__(self, dim, dim_out, noise_level_emb_dim=None, dropout=0, use_affine_level=False,
+                 norm_groups=32, use_checkpoint=False):
+        super().__init__()
+        self.dim, self.dim_out = dim, dim_out
+        self.noise_func = FeatureWiseAffine(noise_level_emb_dim, dim_out, use_affine_level)
+        self.block1 = Block(dim, dim_out, groups=norm_groups)
+        self.block2 = Block(dim_out, dim_out, groups=norm_groups, dropout=dropout)
+        self.res_conv = LazyReshaper2D(nn.Conv2d(dim, dim_out, 1)) if dim != dim_out else nn.Identity()
+        self.plain_off = 0
+        self._pk = None
+
+    def pack(self, dtype, device, split=None):
+        c, co = self.dim, self.dim_out
+        b1, b2 = self.block1.block, self.block2.block
+        self._pk = dict(
+            g1=_dev(b1[0].wrapped_module.weight, device), be1=_dev(b1[0].wrapped_module.bias, device),
+            w1=_pack(b1[3].wrapped_module.weight, [(c, c)], dtype, device), b1=_dev(b1[3].wrapped_module.bias, device),
+            g2=_dev(b2[0].wrapped_module.weight, device), be2=_dev(b2[0].wrapped_module.bias, device),
+            w2=_pack(b2[3].wrapped_module.weight, [(co, co)], dtype, device), b2=_dev(b2[3].wrapped_module.bias, device))
+        if not isinstance(self.res_conv, nn.Identity):
+            segs = [(s, s) for s in (split or [c])]
+            self._pk["ws"] = _pack(self.res_conv.wrapped_module.weight, segs, dtype, device)
+            self._pk["bs"] = _dev(self.res_conv.wrapped_module.bias, device)
+
+    def run(self, ctx, x, x1=None):
+        pk, co = self._pk, self.dim_out
+        g = self.block1.groups
+        eps = self.block1.block[0].wrapped_module.eps
+        h = ops.group_norm(x, pk["g1"], pk["be1"], x1=x1, groups=g, eps=eps, act=A.ACT_SILU)
+        h = ops.conv(h, pk["w1"], pk["b1"], co, (1, 3, 3),
+                     frame_bias=ctx.plain_all[:, self.plain_off:self.plain_off + co])
+        h = ops.group_norm(h, pk["g2"], pk["be2"], groups=g, eps=eps, act=A.ACT_SILU)
+        if "ws" in pk:
+            skip = ops.conv([x] if x1 is None else [x, x1], pk["ws"], pk["bs"], co, (1, 1, 1))
+        else:
+            assert x1 is None
+            skip = x
+        return ops.conv(h, pk["w2"], pk["b2"], co, (1, 3, 3), res0=skip)
+
+
+class ResBlock(nn.Module):
+    """guided_diffusion/unet.py:113-254 as sr3 uses it: dims=3, kernel (3,1,1), no FiLM
+    (``h + emb_out`` before the second norm), identity skip."""
+
+    def __init__(self, channels, emb_channels, dropout, kernel_size=3, padding=1, out_channels=None,
+                 use_scale_shift_norm=False, dims=2, use_checkpoint=False, **kw):
+        super().__init__()
+        if use_scale_shift_norm or (out_channels or channels) != channels:
+            raise NotImplementedError("flair_amd: sr3 uses plain ResBlocks with identity skip")
+        self.channels, self.dims = channels, dims
+        self.kernel = (kernel_size,) * dims if isinstance(kernel_size, int) else tuple(kernel_size)
+        conv = nn.Conv2d if dims == 2 else nn.Conv3d
+        self.in_layers = nn.Sequential(LazyReshaper3D(normalization(channels)), nn.SiLU(),
+                                       PlaceHolder(conv(channels, channels, kernel_size, padding=padding)))
+        self.emb_layers = nn.Sequential(nn.SiLU(), linear(emb_channels, channels))
+        self.out_layers = nn.Sequential(
+            LazyReshaper3D(normalization(channels)), nn.SiLU(), nn.Dropout(p=dropout),
+            zero_module(PlaceHolder(conv(channels, channels, kernel_size, padding=padding))))
+        self.skip_connection = nn.Identity()
+        self.silu_off = 0
+        self._pk = None
+
+    def pack(self, dtype, device):
+        c = self.channels
+        self._pk = dict(
+            g1=_dev(self.in_layers[0].wrapped_module.weight, device), be1=_dev(self.in_layers[0].wrapped_module.bias, device),
+            w1=_pack(self.in_layers[2].wrapped_module.weight, [(c, c)], dtype, device),
+            b1=_dev(self.in_layers[2].wrapped_module.bias, device),
+            g2=_dev(self.out_layers[0].wrapped_module.weight, device), be2=_dev(self.out_layers[0].wrapped_module.bias, device),
+            w2=_pack(self.out_layers[3].wrapped_module.weight, [(c, c)], dtype, device),
+            b2=_dev(self.out_layers[3].wrapped_module.bias, device))
+
+    def run(self, ctx, x):
+        pk, c = self._pk, self.channels
+        k = self.kernel if self.dims == 3 else (1,) + self.kernel
+        eps = self.in_layers[0].wrapped_module.eps
+        h = ops.group_norm(x, pk["g1"], pk["be1"], eps=eps, act=A.ACT_SILU)
+        h = ops.conv(h, pk["w1"], pk["b1"], c, k, frame_bias=ctx.silu_all[:, self.silu_off:self.silu_off + c])
+        h = ops.group_norm(h, pk["g2"], pk["be2"], eps=eps, act=A.ACT_SILU)
+        return ops.conv(h, pk["w2"], pk["b2"], c, k, res0=x)
+
+
+class TemporalWrapper(PlaceHolder):
+    """unet.py:64-77 (learnable scalar gate) -- not used by the shipped sr3 configuration."""
+
+    def __init__(self, module):
+        super().__init__(module)
+        self.weight = nn.Parameter(torch.zeros(1))
+
+
+class TemporalWrapper2(nn.Module):
+    """sr3.py:203-226: (1 - s) x + s module(x), s = sigmoid(Linear(SiLU(emb)))."""
+
+    def __init__(self, module, dim, time_emb_dim=512):
+        super().__init__()
+        self.wrapped_module = module
+        self.dim = dim
+        self.emb_layers = nn.Sequential(nn.SiLU(), zero_module(linear(time_emb_dim, dim)))
+        self.silu_off = 0
+
+    def blend(self, ctx, x, m):
+        return ops.gated_blend(x, m, ctx.silu_all[:, self.silu_off:self.silu_off + self.dim])
+
+
+class FlowVSRPP(BasicVSRPP):
+    """unet.py:313-595: BasicVSRPP holding the shared SPyNet (state-dict compatibility); flows
+    are supplied by the UNet (computed once per clip and resolution)."""
+
+    def __init__(self, mid_channels=64, max_residue_magnitude=10, use_checkpoint=False, shared_spynet=None):
+        super().__init__(mid_channels, max_residue_magnitude, use_checkpoint)
+        self.spynet = shared_spynet
+
+
+class ResnetBlocWithAttn(nn.Module):
+    """sr3.py:229-314."""
+
+    def __init__(self, dim, dim_out, *, noise_level_emb_dim=None, norm_groups=32, dropout=0, conv_3d=False,
+                 spatial_attn=False, temporal_attn=False, conv_3d_kernel_size=(3, 1, 1), num_frames=5,
+                 head_dim=32, vsrpp=False, shared_spynet=None, use_checkpoint=False):
+        super().__init__()
+        if spatial_attn:
+            raise NotImplementedError("flair_amd: sr3 SelfAttention is disabled in FLAIR's configuration")
+        self.spatial_attn = False
+        e = noise_level_emb_dim
+        self.res_block = ResnetBlock(dim, dim_out, e, norm_groups=norm_groups, dropout=dropout)
+        if conv_3d:
+            k = conv_3d_kernel_size
+            self.conv_3d = TemporalWrapper2(
+                ResBlock(dim_out, e, 0.0, dims=3, kernel_size=k, padding=(k[0] // 2, k[1] // 2, k[2] // 2)),
+                dim_out, time_emb_dim=e)
+        if temporal_attn:
+            self.temp_attn = TemporalWrapper2(
+                TemporalAttention(dim_out, num_frames=num_frames, num_heads=8, num_head_channels=head_dim),
+                dim_out, time_emb_dim=e)
+        if vsrpp:
+            self.vsrpp = TemporalWrapper2(FlowVSRPP(dim_out, max_residue_magnitude=5, shared_spynet=shared_spynet),
+                                          dim_out, time_emb_dim=e)
+
+    def run(self, ctx, x, x1=None):
+        x = self.res_block.run(ctx, x, x1)
+        if not ctx.enable_cross_frames:
+            return x
+        if hasattr(self, "conv_3d"):
+            x = self.conv_3d.blend(ctx, x, self.conv_3d.wrapped_module.run(ctx, x))
+        if hasattr(self, "temp_attn"):
+            x = self.temp_attn.blend(ctx, x, self.temp_attn.wrapped_module.run(ctx, x))
+        if hasattr(self, "vsrpp"):
+            x = self.vsrpp.blend(ctx, x, self.vsrpp.wrapped_module.run(ctx, x))
+        return x
+
+
+class Downsample(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.conv = nn.Conv2d(dim, dim, 3, 2, 1)
+
+
+class Upsample(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.up = nn.Upsample(scale_factor=2, mode="nearest")
+        self.conv = nn.Conv2d(dim, dim, 3, padding=1)
+
+
+class UNet(nn.Module):
+    """sr3.py:317-525.  ``timesteps`` is the continuous noise level sqrt(acp_prev)[t+1] that
+    respace._WrappedModel supplies (attribute ``takes_noise_level``)."""
+
+    takes_noise_level = True
+
+    def __init__(self, in_channel=6, out_channel=3, inner_channel=32, norm_groups=32,
+                 channel_mults=(1, 2, 4, 8, 8), attn_res=(8,), vsrpp_res=(64,), spatial_attn=False,
+                 temporal_attn=False, res_blocks=3, dropout=0, with_noise_level_emb=True, image_size=128,
+                 dtype=torch.float32, cross_frame_module=False, use_checkpoint=False, num_frames=5, head_dim=32):
+        super().__init__()
+        if spatial_attn or not with_noise_level_emb:
+            raise NotImplementedError("flair_amd: sr3.UNet covers FLAIR's configuration "
+                                      "(spatial_attn=False, with_noise_level_emb=True)")
+        self.in_channel, self.out_channel, self.inner_channel = in_channel, out_channel, inner_channel
+        self.image_size = image_size
+        self.dtype = torch.bfloat16 if dtype in (torch.float16, torch.bfloat16) else torch.float32
+        shared = SPyNet(pretrained=None) if len(vsrpp_res) > 0 else None
+        self._shared_spynet = [shared]          # not a registered child here (as in the reference)
+        e = inner_channel
+        self.noise_level_mlp = nn.Sequential(PositionalEncoding(inner_channel), nn.Linear(inner_channel, inner_channel * 4),
+                                             Swish(), nn.Linear(inner_channel * 4, inner_channel))
+
+        def blk(cin, cout, res):
+            return ResnetBlocWithAttn(
+                cin, cout, noise_level_emb_dim=e, norm_groups=norm_groups, dropout=dropout, conv_3d=cross_frame_module,
+                temporal_attn=(res in attn_res and temporal_attn and cross_frame_module), num_frames=num_frames,
+                head_dim=head_dim, vsrpp=(res in vsrpp_res and cross_frame_module),
+                shared_spynet=shared if (res in vsrpp_res and cross_frame_module) else None)
+
+        pre, res = inner_channel, image_size
+        feats = [pre]
+        downs = [LazyReshaper2D(nn.Conv2d(in_channel, inner_channel, kernel_size=3, padding=1))]
+        n = len(channel_mults)
+        for i in range(n):
+            ch = inner_channel * channel_mults[i]
+            for _ in range(res_blocks):
+                downs.append(blk(pre, ch, res))
+                feats.append(ch)
+                pre = ch
+            if i != n - 1:
+                downs.append(LazyReshaper2D(Downsample(pre)))
+                feats.append(pre)
+                res //= 2
+        self.downs = nn.ModuleList(downs)
+        mk = dict(noise_level_emb_dim=e, norm_groups=norm_groups, dropout=dropout, conv_3d=cross_frame_module,
+                  temporal_attn=temporal_attn and cross_frame_module, num_frames=num_frames, head_dim=head_dim)
+        self.mid = nn.ModuleList([ResnetBlocWithAttn(pre, pre, **mk), ResnetBlocWithAttn(pre, pre, **mk)])
+        ups, self._skip_split = [], {}
+        for i in reversed(range(n)):
+            ch = inner_channel * channel_mults[i]
+            for _ in range(res_blocks + 1):
+                skip = feats.pop()
+                b = blk(pre + skip, ch, res)
+                self._skip_split[id(b.res_block)] = [pre, skip]
+                ups.append(b)
+                pre = ch
+            if i >= 1:
+                ups.append(LazyReshaper2D(Upsample(pre)))
+                res *= 2
+        self.ups = nn.ModuleList(ups)
+        self.final_conv = Block(pre, out_channel if out_channel is not None else in_channel, groups=norm_groups)
+        self._packed_key = None
+        self._flow_cache = {}
+
+    # ---- dtype management --------------------------------------------------------------
+    def convert_to_fp16(self):
+        self.dtype = torch.bfloat16
+        self._packed_key = None
+
+    def convert_to_fp32(self):
+        self.dtype = torch.float32
+        self._packed_key = None
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self._packed_key = None
+        return out
+
+    # ---- packing -----------------------------------------------------------------------
+    def _ensure_packed(self, device):
+        key = (self.dtype, device)
+        if self._packed_key == key:
+            return
+        dt = self.dtype
+        stem = self.downs[0].wrapped_module
+        stem._pk_w = _pack(stem.weight, [(self.in_channel, ops.pad_channels(self.in_channel, dt))], dt, device)
+        stem._pk_b = _dev(stem.bias, device)
+        plain_w, plain_b, silu_w, silu_b = [], [], [], []
+        po = so = 0
+        for m in self.modules():
+            if isinstance(m, ResnetBlock):
+                m.pack(dt, device, self._skip_split.get(id(m)))
+                lin = m.noise_func.noise_func[0]
+                m.plain_off = po
+                plain_w.append(_dev(lin.weight, device)); plain_b.append(_dev(lin.bias, device))
+                po += lin.out_features
+            elif isinstance(m, (ResBlock, TemporalWrapper2)):
+                if isinstance(m, ResBlock):
+                    m.pack(dt, device)
+                lin = m.emb_layers[1]
+                m.silu_off = so
+                silu_w.append(_dev(lin.weight, device)); silu_b.append(_dev(lin.bias, device))
+                so += lin.out_features
+            elif isinstance(m, (TemporalAttention, BasicVSRPP)):
+                m.pack(dt, device)
+            elif isinstance(m, (Downsample, Upsample)):
+                c = m.conv.in_channels
+                m._pk_w = _pack(m.conv.weight, [(c, c)], dt, device)
+                m._pk_b = _dev(m.conv.bias, device)
+        self._plain = (torch.cat(plain_w).contiguous(), torch.cat(plain_b).contiguous())
+        self._silu = (torch.cat(silu_w).contiguous(), torch.cat(silu_b).contiguous())
+        if self._shared_spynet[0] is not None:
+            self._shared_spynet[0].to(device)
+            self._shared_spynet[0].pack(device)
+        mlp = self.noise_level_mlp
+        self._mlp = [_dev(p, device) for p in (mlp[1].weight, mlp[1].bias, mlp[3].weight, mlp[3].bias)]
+        fc = self.final_conv.block
+        cout = self.out_channel if self.out_channel is not None else self.in_channel
+        cpad = (cout + 3) // 4 * 4
+        cin = fc[3].wrapped_module.in_channels
+        self._fin = dict(g=_dev(fc[0].wrapped_module.weight, device), be=_dev(fc[0].wrapped_module.bias, device),
+                         w=_pack(fc[3].wrapped_module.weight, [(cin, cin)], dt, device, cout_pad=cpad),
+                         b=torch.cat([_dev(fc[3].wrapped_module.bias, device),
+                                      torch.zeros(cpad - cout, device=device)]).contiguous(), cout=cout, cpad=cpad)
+        self._packed_key = key
+        self._flow_cache = {}
+
+    # ---- flows: once per (clip, resolution) ----------------------------------------------
+    def _flows_for(self, rnn_clip, resolutions):
+        key = (rnn_clip.data_ptr(), rnn_clip._version, tuple(rnn_clip.shape))
+        hit = self._flow_cache.get(key)
+        if hit is None:
+            sp = self._shared_spynet[0]
+            flows = {}
+            for r in resolutions:
+                src = rnn_clip if rnn_clip.shape[-1] == r else aa_resize(rnn_clip, r)
+                T = src.shape[0]
+                raw = torch.zeros((T, r, r, 4), dtype=torch.float32, device=src.device)
+                ops.nchw_to_clip(src.contiguous(), raw, 0)
+                norm = torch.zeros_like(raw)
+                ops.affine_channels(raw, 3, 0.5, 0.5, 0.0, 1.0, sp._pk["mean"], sp._pk["istd"], norm)
+                a, b = norm[:-1], norm[1:]
+                flows[r] = (sp.run(b, a), sp.run(a, b))       # (forward, backward)
+            if len(self._flow_cache) >= 16:
+                self._flow_cache.clear()
+            hit = (flows, rnn_clip)
+            self._flow_cache[key] = hit
+        return hit[0]
+
+    # ---- forward -------------------------------------------------------------------------
+    def forward(self, x, timesteps, low_res_input=None, rnn_input=None, num_frames=None,
+                enable_cross_frames=True, vsrpp_weights=None, **kwargs):
+        if not x.is_cuda:
+            raise RuntimeError("flair_amd.sr3.UNet runs on the MI355X only (tensors must be on 'cuda'); "
+                               "there is no CPU path")
+        self._ensure_packed(x.device)
+        T = int(num_frames)
+        B = x.shape[0] // T
+        if rnn_input is None:
+            rnn_input = low_res_input
+        outs = []
+        for b in range(B):
+            vw = vsrpp_weights[b] if isinstance(vsrpp_weights, torch.Tensor) else vsrpp_weights
+            outs.append(self._forward_clip(x[b * T:(b + 1) * T].float().contiguous(),
+                                           timesteps[b * T:(b + 1) * T].float().contiguous(),
+                                           low_res_input[b].float().contiguous(), rnn_input[b].float(),
+                                           enable_cross_frames, vw))
+        return outs[0] if B == 1 else torch.cat(outs, dim=0)
+
+    def _forward_clip(self, x, level, low_res, rnn, enable_cross_frames, vsrpp_weights):
+        T, _, H, W = x.shape
+        dev, dt = x.device, self.dtype
+        ctx = Ctx(dt, dev, T)
+        ctx.enable_cross_frames = enable_cross_frames
+        ctx.vsrpp_weights = vsrpp_weights
+        res_needed = sorted({r for r, _ in self._vsrpp_levels(H)}) if enable_cross_frames else []
+        ctx.flows = self._flows_for(rnn, res_needed) if res_needed else {}
+        pe = ops.timestep_embedding(level, self.inner_channel, sin_first=True)
+        e = ops.linear(pe, self._mlp[0], self._mlp[1], act_out=A.ACT_SILU)
+        emb = ops.linear(e, self._mlp[2], self._mlp[3])
+        ctx.plain_all = ops.linear(emb, self._plain[0], self._plain[1])
+        ctx.silu_all = ops.linear(emb, self._silu[0], self._silu[1], act_in=A.ACT_SILU)
+        cin = ops.pad_channels(self.in_channel, dt)
+        h = torch.zeros((T, H, W, cin), dtype=dt, device=dev)
+        ops.nchw_to_clip(low_res, h, 0)
+        ops.nchw_to_clip(x, h, low_res.shape[1])
+        feats = []
+        for layer in self.downs:
+            h = self._run_layer(ctx, layer, h)
+            feats.append(h)
+        for layer in self.mid:
+            h = layer.run(ctx, h)
+        for layer in self.ups:
+            if isinstance(layer, ResnetBlocWithAttn):
+                h = layer.run(ctx, h, feats.pop())
+            else:
+                h = self._run_layer(ctx, layer, h)
+        f = self._fin
+        g = self.final_conv.groups
+        h = ops.group_norm(h, f["g"], f["be"], groups=g, eps=self.final_conv.block[0].wrapped_module.eps,
+                           act=A.ACT_SILU)
+        y = ops.conv(h, f["w"], f["b"], f["cpad"], (1, 3, 3))
+        return ops.clip_to_nchw(y, f["cout"])
+
+    def _vsrpp_levels(self, size):
+        """(resolution, module) of every BasicVSRPP in the network for an input of side `size`."""
+        out, res = [], size
+        for layer in self.downs:
+            if isinstance(layer, ResnetBlocWithAttn):
+                if hasattr(layer, "vsrpp"):
+                    out.append((res, layer.vsrpp.wrapped_module))
+            elif isinstance(layer.wrapped_module, Downsample):
+                res //= 2
+        for layer in self.ups:
+            if isinstance(layer, ResnetBlocWithAttn):
+                if hasattr(layer, "vsrpp"):
+                    out.append((res, layer.vsrpp.wrapped_module))
+            elif isinstance(layer.wrapped_module, Upsample):
+                res *= 2
+        return out
+
+    def _run_layer(self, ctx, layer, h):
+        if isinstance(layer, ResnetBlocWithAttn):
+            return layer.run(ctx, h)
+        inner = layer.wrapped_module
+        if isinstance(inner, nn.Conv2d):
+            return ops.conv(h, inner._pk_w, inner._pk_b, inner.out_channels, (1, 3, 3))
+        if isinstance(inner, Downsample):
+            return ops.conv(h, inner._pk_w, inner._pk_b, inner.conv.out_channels, (1, 3, 3), stride=2)
+        if isinstance(inner, Upsample):
+            T, H, W, C = h.shape
+            up = ops.resize(h, (2 * H, 2 * W), ops.RESIZE_NEAREST)
+            return ops.conv(up, inner._pk_w, inner._pk_b, inner.conv.out_channels, (1, 3, 3))
+        raise TypeError(f"flair_amd: no executor for {type(inner).__name__}")

@@ -87,7 +87,7 @@ def pad_channels(c, dtype):
 
 # --------------------------------------------------------------------------- conv
 def conv(xs, weight, bias, cout, kernel, *, out=None, act=ACT_NONE, res0=None, res1=None,
-         out_scale=1.0):
+         out_scale=1.0, stride=1, frame_bias=None):
     """Y = act(conv(cat(xs), W) + bias) + res0 + res1, times out_scale.
 
     xs: one clip tensor or a list of up to 4 (channel-concatenated implicitly; each
@@ -110,9 +110,14 @@ def conv(xs, weight, bias, cout, kernel, *, out=None, act=ACT_NONE, res0=None, r
         p.seg_c[i] = x.shape[3]
         p.seg_ld[i] = _ld(x)
         arr[i] = x.data_ptr()
+    p.stride = stride
+    p.frame_bias_ld = frame_bias.stride(0) if frame_bias is not None else 0
+    if frame_bias is not None:
+        assert frame_bias.dtype == torch.float32 and frame_bias.stride(1) == 1 and frame_bias.shape[0] == T
+    Ho, Wo = (H + stride - 1) // stride, (W + stride - 1) // stride
     if out is None:
-        out = torch.empty((T, H, W, cout), dtype=x0.dtype, device=x0.device)
-    assert out.shape[:3] == x0.shape[:3] and out.shape[3] >= cout and out.dtype == x0.dtype
+        out = torch.empty((T, Ho, Wo, cout), dtype=x0.dtype, device=x0.device)
+    assert tuple(out.shape[:3]) == (T, Ho, Wo) and out.shape[3] >= cout and out.dtype == x0.dtype
     p.y_ld = _ld(out)
     p.res_ld[0] = _ld(res0) if res0 is not None else 0
     p.res_ld[1] = _ld(res1) if res1 is not None else 0
@@ -125,12 +130,12 @@ def conv(xs, weight, bias, cout, kernel, *, out=None, act=ACT_NONE, res0=None, r
         e0.record()
     wsb = _conv_ws_bytes(p)
     ws = _workspace(wsb, x0.device, "conv") if wsb else None
-    check(lib().flair_conv_nhwc(ctypes.byref(p), arr, ptr(weight), ptr(_f32(bias)), ptr(res0),
+    check(lib().flair_conv_nhwc(ctypes.byref(p), arr, ptr(weight), ptr(_f32(bias)), ptr(frame_bias), ptr(res0),
                                 ptr(res1), ptr(out), ptr(ws), ctypes.c_size_t(wsb), stream()), "flair_conv_nhwc")
     if prof is not None:
         e1.record()
         cin = sum(x.shape[3] for x in xs)
-        flops = 2.0 * T * H * W * cout * cin * kernel[0] * kernel[1] * kernel[2]
+        flops = 2.0 * T * Ho * Wo * cout * cin * kernel[0] * kernel[1] * kernel[2]
         prof.append((lib().flair_conv_variant(ctypes.byref(p)), str(x0.dtype), flops, e0, e1))
     return out
 
@@ -244,14 +249,14 @@ def clip_to_nchw(src, C, coff=0, out=None):
     return out
 
 
-def timestep_embedding(t, dim, max_period=10000.0, out=None):
-    """t: (N,) f32 device tensor -> (N, dim) f32."""
+def timestep_embedding(t, dim, max_period=10000.0, out=None, sin_first=False):
+    """t: (N,) f32 device tensor -> (N, dim) f32 ([cos|sin], or [sin|cos] when sin_first)."""
     assert t.dtype == torch.float32 and t.is_contiguous()
     N = t.shape[0]
     if out is None:
         out = torch.empty((N, dim), dtype=torch.float32, device=t.device)
-    check(lib().flair_timestep_embedding(ptr(t), N, dim, ctypes.c_float(max_period), ptr(out), stream()),
-          "flair_timestep_embedding")
+    check(lib().flair_timestep_embedding(ptr(t), N, dim, ctypes.c_float(max_period), int(sin_first), ptr(out),
+                                         stream()), "flair_timestep_embedding")
     return out
 
 
@@ -497,3 +502,14 @@ def vsrpp_prep(prop, feat2, flow1, flow_prev, cond1, cond2, flow2_out, flowpad):
                                  dtype_code(prop), H, W, C, ptr(cond1), _ld(cond1), ptr(cond2 if second else None),
                                  _ld(cond2) if second else 0, ptr(flow2_out if second else None), ptr(flowpad),
                                  _ld(flowpad), stream()), "flair_vsrpp_prep")
+
+
+def gated_blend(x, m, gate, out=None):
+    """x + sigmoid(gate[f, c]) * (m - x); gate: (F, >=C) f32 logits."""
+    T, H, W, C = x.shape
+    assert gate.dtype == torch.float32 and gate.stride(1) == 1 and gate.shape[0] == T
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib().flair_gated_blend(ptr(x), _ld(x), ptr(m), _ld(m), ptr(gate), gate.stride(0), dtype_code(x), C, T,
+                                  ctypes.c_long(H * W), ptr(out), _ld(out), stream()), "flair_gated_blend")
+    return out

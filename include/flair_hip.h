@@ -66,6 +66,8 @@ int flair_abi_version(void);
  *            th.cat (seg_c[i] must be a multiple of 32 (bf16) / 16 (f32); pad with zeros)
  *   w      : [Cout][KT*KH*KW][sum seg_c] in the activation dtype
  *   bias   : [Cout] f32 or NULL;  res0/res1: [T][H][W][Cout-slice] or NULL
+ *   frame_bias : [T][frame_bias_ld] f32 or NULL, added before the activation (the per-frame
+ *            embedding terms `h + emb_out` of unet.py:246 and sr3.py:82)
  *   y      : [T][H][W] pixels, y_ld elements apart, Cout (multiple of 4) written per pixel
  *   workspace : optional device scratch of flair_conv_workspace_bytes(p) bytes; when given,
  *            deep-K convolutions on few pixels (the 16x16..4x4 levels) are split over K
@@ -82,12 +84,15 @@ typedef struct {
     int res_ld[2];
     int act;
     float out_scale;
+    int frame_bias_ld;
+    int stride; /* spatial stride 1 (default when 0) or 2: T,H,W describe the INPUT, the output is
+                 * ceil(H/stride) x ceil(W/stride) (PyTorch Conv2d(k, stride, padding=k//2)) */
 } flair_conv_params;
 
 size_t flair_conv_workspace_bytes(const flair_conv_params* p);
 int flair_conv_nhwc(const flair_conv_params* p, const void* const* x, const void* w,
-                    const float* bias, const void* res0, const void* res1, void* y,
-                    void* workspace, size_t workspace_bytes, hipStream_t stream);
+                    const float* bias, const float* frame_bias, const void* res0, const void* res1,
+                    void* y, void* workspace, size_t workspace_bytes, hipStream_t stream);
 /* Which kernel variant flair_conv_nhwc launches for these parameters (profiling aid):
  * im2col tiles 0 = 128 couts x 128 pixels, 1 = 64 x 128, 2 = 64 x 64 per workgroup;
  * halo kernel (3x3 spatial taps, W % 32 == 0) 3 / 4 / 5 = 8 / 4 / 2 image rows per workgroup. */
@@ -133,9 +138,10 @@ int flair_nchw_f32_to_nhwc(const float* src, int N, int C, int H, int W, void* d
 int flair_nhwc_to_nchw_f32(const void* src, int dtype, int src_ld, int src_coff, int N, int C,
                            int H, int W, float* dst, hipStream_t stream);
 
-/* timestep_embedding (nn_new.py:103-121): out[n] = [cos(t_n f_i) | sin(t_n f_i)], f32. */
-int flair_timestep_embedding(const float* t, int N, int dim, float max_period, float* out,
-                             hipStream_t stream);
+/* timestep_embedding (nn_new.py:103-121): out[n] = [cos(t_n f_i) | sin(t_n f_i)], f32;
+ * sin_first != 0 gives sr3's PositionalEncoding order [sin | cos] (sr3.py:45-60). */
+int flair_timestep_embedding(const float* t, int N, int dim, float max_period, int sin_first,
+                             float* out, hipStream_t stream);
 
 /* y = act_out(act_in(x) @ w^T + bias), f32, M <= 32 rows (one per frame).  Replaces the
  * time_embed MLP (unet_new.py:980-984,1351) and every emb_layers Linear (:258-264,:399). */
@@ -177,6 +183,10 @@ int flair_learned_range_variance(const float* model_out, int N, int C, int H, in
 int flair_affine_channels_f32(const float* x, int x_ld, int C, long P, float a, float b, float lo,
                               float hi, const float* sub, const float* mul, float* y, int y_ld,
                               hipStream_t stream);
+/* y = x + sigmoid(gate[f][c]) * (m - x): TemporalWrapper2's emb-gated residual mix
+ * (sr3.py:203-226).  x, m, y: [F][HW] pixels of C channels; gate: [F][gate_ld] f32 logits. */
+int flair_gated_blend(const void* x, int x_ld, const void* m, int m_ld, const float* gate, int gate_ld,
+                      int dtype, int C, int F, long HW, void* y, int y_ld, hipStream_t stream);
 /* x[f][p][c] += bias[f][c]  (AttentionbottleBlock h + emb_out, unet_new.py:426-428). */
 int flair_add_frame_bias(void* x, int dtype, int ld, int C, int F, long HW, const float* bias,
                          int bias_ld, hipStream_t stream);

@@ -73,7 +73,9 @@ class ResBlock(nn.Module):
     to both branches before the first conv (unet_new.py:310-315)."""
 
     def __init__(self, channels, emb_channels, out_channels=None, dims=2,
-                 use_scale_shift_norm=True, up=False, down=False):
+                 use_scale_shift_norm=True, up=False, down=False, kernel_size=3, padding=1):
+        """kernel_size / padding: the guided_diffusion/unet.py:113-254 variant used by sr3
+        (e.g. a (3,1,1) temporal kernel); 3 / 1 reproduces unet_new.py."""
         super().__init__()
         out_channels = out_channels or channels
         self.channels, self.out_channels, self.dims = channels, out_channels, dims
@@ -82,13 +84,13 @@ class ResBlock(nn.Module):
         conv = nn.Conv2d if dims == 2 else nn.Conv3d
         self.in_layers = nn.Sequential(
             Wrapped(nn.GroupNorm(32, channels)), nn.SiLU(),
-            Wrapped(conv(channels, out_channels, 3, padding=1)))
+            Wrapped(conv(channels, out_channels, kernel_size, padding=padding)))
         self.emb_layers = nn.Sequential(
             nn.SiLU(), nn.Linear(emb_channels, 2 * out_channels if use_scale_shift_norm
                                  else out_channels))
         self.out_layers = nn.Sequential(
             Wrapped(nn.GroupNorm(32, out_channels)), nn.SiLU(), nn.Dropout(0.0),
-            _zero(Wrapped(conv(out_channels, out_channels, 3, padding=1))))
+            _zero(Wrapped(conv(out_channels, out_channels, kernel_size, padding=padding))))
         if out_channels == channels:
             self.skip_connection = nn.Identity()
         else:

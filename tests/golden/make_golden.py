@@ -156,6 +156,40 @@ def main():
     emb = nn_new.timestep_embedding(torch.tensor([0., 1., 37., 999., 500.5]), 128)
     save("g4_timestep_embedding", t=np.array([0., 1., 37., 999., 500.5]), emb=emb)
 
+    # ---- G7: sr3.UNet (bicubic tasks), small configuration ---------------------------------
+    sr3 = refimport.ref("sr3")
+    SR3_SMALL = dict(image_size=64, in_channel=6, out_channel=3, inner_channel=64, norm_groups=16,
+                     channel_mults=(1, 2, 4), attn_res=(32, 16), vsrpp_res=(64,), spatial_attn=False,
+                     temporal_attn=True, res_blocks=1, dropout=0.0, dtype=torch.float32, cross_frame_module=True,
+                     use_checkpoint=False, num_frames=7, head_dim=64)
+    with refimport.cuda_shaped():
+        m3 = sr3.UNet(**SR3_SMALL)
+    name_seeded_weights(m3)
+    m3.eval()
+    gen = torch.Generator().manual_seed(5)
+    x3 = torch.randn(4, 3, 64, 64, generator=gen)
+    base3 = torch.rand(3, 64, 64, generator=gen) * 2 - 1
+    lr3 = torch.stack([torch.roll(base3, shifts=(i, 2 * i), dims=(1, 2)) for i in range(4)])[None]
+    lr3 = (lr3 + 0.05 * torch.randn(1, 4, 3, 64, 64, generator=gen)).clamp(-1, 1)
+    lv3 = torch.full((4,), 0.83)
+    y3 = m3(x3, lv3, low_res_input=lr3, num_frames=4, vsrpp_weights=0.93)
+    # the _WrappedModel path for SR3: continuous noise level sqrt(acp_prev)[t+1]
+    d3 = rs.SpacedDiffusion(use_timesteps=rs.space_timesteps(2000, "100", "uniform"),
+                            betas=gd.get_named_beta_schedule("face_bicubic", 2000),
+                            model_mean_type=gd.ModelMeanType.EPSILON, model_var_type=gd.ModelVarType.FIXED_SMALL,
+                            loss_type=gd.LossType.MSE)
+    seen = {}
+
+    class Probe(sr3.UNet):
+        def __init__(self):
+            torch.nn.Module.__init__(self)
+
+        def forward(self, x, level, **kw):
+            seen["level"] = level
+            return torch.zeros_like(x)
+    d3._wrap_model(Probe())(x3, torch.tensor([0, 17, 50, 99]))
+    save("g7_sr3_small", x=x3, lr=lr3, level=lv3, y=y3, wrapped_levels=seen["level"])
+
     # ---- G6: degradation operators ------------------------------------------------------
     import scipy.io
     jp = refimport.ref("jpeg")

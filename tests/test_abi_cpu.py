@@ -48,5 +48,5 @@ def test_argument_errors_are_reported_without_a_gpu():
     p = _lib.ConvParams()
     p.dtype = 7
     rc = lib.flair_conv_nhwc(ctypes.byref(p), (ctypes.c_void_p * 4)(1, 0, 0, 0), ctypes.c_void_p(16), None, None,
-                             None, ctypes.c_void_p(16), None, ctypes.c_size_t(0), None)
+                             None, None, ctypes.c_void_p(16), None, ctypes.c_size_t(0), None)
     assert rc == -1 and b"bad dtype" in lib.flair_last_error()

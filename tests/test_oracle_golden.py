@@ -187,3 +187,36 @@ def test_resizer():
     img, low = torch.from_numpy(g["img"]), torch.from_numpy(g["low"])
     assert np.abs(od.resize_apply(img, 1 / 8).numpy() - g["resizer_down8"]).max() <= 1e-5
     assert np.abs(od.resize_apply(low, 8).numpy() - g["resizer_up8"]).max() <= 1e-5
+
+
+def test_sr3_small_and_wrapped_noise_level():
+    """Oracle sr3.UNet vs the reference's forward, and the SR3 branch of _WrappedModel
+    (respace.py:161-165: continuous level sqrt(acp_prev)[t+1]) for the oracle and the product."""
+    from oracle.sr3 import UNet
+    from oracle import diffusion as od
+    from flair_amd.guided_diffusion import gaussian_diffusion as gd
+    from flair_amd.guided_diffusion import respace as rs
+    from tests.test_gpu_sr3 import SR3_SMALL
+    g = load("g7_sr3_small")
+    o = name_seeded_weights(UNet(**SR3_SMALL)).eval()
+    with torch.no_grad():
+        y = o(torch.from_numpy(g["x"]), torch.from_numpy(g["level"]), low_res_input=torch.from_numpy(g["lr"]),
+              num_frames=4, vsrpp_weights=0.93)
+    assert np.abs(y.numpy() - g["y"]).max() <= 1e-5 * np.abs(g["y"]).max()
+    ts = torch.tensor([0, 17, 50, 99])
+    tab = od.Spaced(od.spaced_steps(2000, "100"), od.named_betas("face_bicubic", 2000))
+    assert np.array_equal(np.float32(tab.sqrt_alphas_cumprod_prev)[ts + 1], g["wrapped_levels"])
+    d = rs.SpacedDiffusion(use_timesteps=rs.space_timesteps(2000, "100", "uniform"),
+                           betas=gd.get_named_beta_schedule("face_bicubic", 2000),
+                           model_mean_type=gd.ModelMeanType.EPSILON, model_var_type=gd.ModelVarType.FIXED_SMALL,
+                           loss_type=gd.LossType.MSE)
+    seen = {}
+
+    class Probe:
+        takes_noise_level = True
+
+        def __call__(self, x, level, **kw):
+            seen["level"] = level
+            return x
+    d._wrap_model(Probe())(torch.zeros(4, 3, 2, 2), ts)
+    assert np.array_equal(seen["level"].numpy(), g["wrapped_levels"])
