@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--task", default="gaussian", choices=["gaussian", "jpeg"])
+    ap.add_argument("--task", default="gaussian", choices=["gaussian", "jpeg", "x8_bicubic", "x16_bicubic"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -100,32 +100,50 @@ def main():
 
     S, T = a.size, a.frames
     hp = wl.TASKS[a.task]
+    bicubic = "bicubic" in a.task
     torch.manual_seed(0)
-    model = UNetModel(**wl.blur_config(S, use_fp16=(a.dtype == "bf16")))
+    if bicubic:
+        from flair_amd.guided_diffusion.restore_util import SRConv
+        from flair_amd.guided_diffusion.sr3 import UNet as BicubicUNet
+        model = BicubicUNet(**wl.sr3_config(S, use_fp16=(a.dtype == "bf16")))
+    else:
+        model = UNetModel(**wl.blur_config(S, use_fp16=(a.dtype == "bf16")))
     if rank == 0:
         wl.randomize_zero_modules(model)
     model = model.to(dev).eval()
     t_bcast = parallel.broadcast_weights(model, src=0) if world > 1 else 0.0
     if a.dtype == "bf16":
         model.convert_to_fp16()
-    diffusion = wl.diffusion_for(TOTAL_STEPS)
-    conf = psr.Get_pseudoSR_Conf(4)
-    A_func = psr.pseudoSR(conf, upscale_kernel=wl.synthetic_blur_kernel(), kernel_indx=10).WrapArchitecture_PyTorch().to(dev)
-
     clip_id = rank                                     # weak scaling: one clip per GPU
     degraded, init, rnn = (v.to(dev) for v in wl.clip_inputs(a.task, clip_id, T, S))
     lr_flat = degraded[0].contiguous()
     qf = hp["jpeg_qf"]
+    if bicubic:
+        diffusion = wl.bicubic_diffusion_for(TOTAL_STEPS)
+        A_func = SRConv(wl.bicubic_taps(hp["factor"]), 3, S, dev, stride=hp["factor"])
+        d_flat = lr_flat.reshape(T, -1)
 
-    def restore_fn(x0):
-        return A_func.A_pinv(lr_flat, x0,
-                             jpeg_encode=(lambda im: jpeg_encode(im, qf)) if qf != -1 else None,
-                             jpeg_decode=(lambda im: jpeg_decode(im, qf)) if qf != -1 else None)
+        def restore_fn(x0):                            # bicubic_restore, scripts/video_sample.py:177-181
+            return A_func.A_pinv(ops.axpby(A_func.A(x0.reshape(T, -1)), d_flat, 1.0, -1.0)).reshape(x0.shape)
+    else:
+        diffusion = wl.diffusion_for(TOTAL_STEPS)
+        conf = psr.Get_pseudoSR_Conf(4)
+        A_func = psr.pseudoSR(conf, upscale_kernel=wl.synthetic_blur_kernel(),
+                              kernel_indx=10).WrapArchitecture_PyTorch().to(dev)
+
+        def restore_fn(x0):
+            return A_func.A_pinv(lr_flat, x0,
+                                 jpeg_encode=(lambda im: jpeg_encode(im, qf)) if qf != -1 else None,
+                                 jpeg_decode=(lambda im: jpeg_decode(im, qf)) if qf != -1 else None)
 
     g = torch.Generator(device=dev).manual_seed(4321 + clip_id)
     tt = torch.full((T,), diffusion.num_timesteps - 1, device=dev, dtype=torch.long)
     x_T = diffusion.q_sample(init[0].contiguous(), tt, noise=torch.randn(T, 3, S, S, device=dev, generator=g))
-    kwargs = dict(low_res_input=init, num_frames=T, enable_cross_frames=True, vsrpp_weights=1.0, rnn_input=rnn)
+    if bicubic:
+        kwargs = dict(low_res_input=init, num_frames=T, enable_cross_frames=True,
+                      vsrpp_weights=wl.face_weight_map(T, S, hp["face_weight"]).to(dev))
+    else:
+        kwargs = dict(low_res_input=init, num_frames=T, enable_cross_frames=True, vsrpp_weights=1.0, rnn_input=rnn)
 
     W = max(0, a.warmup)
     K = max(1, min(a.steps, TOTAL_STEPS - W - 1))      # keep one step for the instrumented pass
@@ -190,8 +208,10 @@ def main():
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": f"{a.task}-demo, {world} clip(s) x {T} frames x {S}x{S}, "
-                               f"{TOTAL_STEPS}-step generalised DDIM (rho={hp['rho']}), unet_new.UNetModel "
-                               f"405.6M params random init, blur x4 restore_fn on GPU, one clip per GPU",
+                               f"{TOTAL_STEPS}-step generalised DDIM (rho={hp['rho']}), "
+                               + ("sr3.UNet random init, SRConv bicubic restore_fn on GPU" if bicubic else
+                                  "unet_new.UNetModel 405.6M params random init, blur x4 restore_fn on GPU")
+                               + ", one clip per GPU",
                    "steps_per_clip": TOTAL_STEPS, "value_definition": "n_gpus*frames/(250*mean timed step)",
                    "finite_output": finite, "weight_broadcast_s": t_bcast},
         "roofline": {"bound": "mfma", "kernel": CONV_VARIANTS.get(key[0], str(key[0])) + " " + key[1],

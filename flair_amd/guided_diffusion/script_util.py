@@ -2,8 +2,8 @@
 
 Differences, all forced by the BASELINE configurations: ``image_size`` is honoured (the
 reference hard-codes 512 in ``create_model``, script_util.py:178-230, which breaks the flow
-lookup for any other clip size); the bicubic (SR3) network is a
-later row of the scope table and raises NotImplementedError for now.
+lookup for any other clip size); for the bicubic (SR3) network the
+attention / BasicVSR++ resolutions scale with ``image_size`` the same way.
 """
 import argparse
 
@@ -49,8 +49,16 @@ def create_model(task, image_size, num_channels, num_res_blocks, channel_mult=""
     if task == "face_blur":
         return BlurUNet(**blur_unet_config(image_size, use_fp16, cross_frame_module, use_checkpoint))
     if task == "face_bicubic":
-        raise NotImplementedError("flair_amd: the SR3 bicubic UNet (guided_diffusion/sr3.py) is a 'next' "
-                                  "row of the hot-path scope table and is not built yet")
+        import torch
+        from .sr3 import UNet as BicubicUNet
+        attn_res = (image_size // 8, image_size // 16) if rebuttal in ("none", "attn") else ()
+        vsrpp_res = (image_size, image_size // 2) if rebuttal in ("none", "rnn") else ()
+        return BicubicUNet(image_size=image_size, in_channel=6, out_channel=3, inner_channel=64, norm_groups=16,
+                           channel_mults=(1, 2, 4, 8, 16), attn_res=attn_res, vsrpp_res=vsrpp_res,
+                           spatial_attn=False, temporal_attn=cross_frame_module, res_blocks=1, dropout=0.0,
+                           dtype=torch.float16 if use_fp16 else torch.float32,
+                           cross_frame_module=cross_frame_module, use_checkpoint=use_checkpoint, num_frames=7,
+                           head_dim=64)
     return None
 
 

@@ -12,9 +12,11 @@ import torch
 import torch.nn.functional as F
 
 TASKS = {
-    # task: (w, rho, noise_level, zeta, jpeg_qf)
-    "gaussian": dict(w=0.75, rho=0.25, noise_level=2.55, zeta=1.0, jpeg_qf=-1),
-    "jpeg": dict(w=0.5, rho=0.5, noise_level=12.75, zeta=1.0, jpeg_qf=60),
+    # demo hyper-parameters of scripts/video_sample.py:499-556
+    "gaussian": dict(w=0.75, rho=0.25, noise_level=2.55, zeta=1.0, jpeg_qf=-1, factor=4),
+    "jpeg": dict(w=0.5, rho=0.5, noise_level=12.75, zeta=1.0, jpeg_qf=60, factor=4),
+    "x8_bicubic": dict(w=0.85, rho=0.85, noise_level=0.0, zeta=-1, jpeg_qf=-1, factor=8, face_weight=0.93),
+    "x16_bicubic": dict(w=0.7, rho=0.85, noise_level=0.0, zeta=-1, jpeg_qf=-1, factor=16, face_weight=0.98),
 }
 
 
@@ -35,13 +37,17 @@ def randomize_zero_modules(model, seed=1):
                 p.copy_(torch.randn(p.shape, generator=g) * 0.02)
 
 
-def clip_inputs(task, clip_id, frames, size, lr_factor=4):
+def clip_inputs(task, clip_id, frames, size, lr_factor=None):
     """Host tensors of one synthetic clip: degraded (1,T,3,s,s) in [-1,1], init (1,T,3,S,S) in
-    [-1,1], rnn_input (1,T,3,S,S), noise seed."""
+    [-1,1] (INIT_FUNC of scripts/video_sample.py:158-163: area resize for the blur tasks, bicubic
+    for the bicubic tasks), rnn_input (1,T,3,S,S)."""
     g = torch.Generator().manual_seed(1234 + clip_id)
-    s = size // lr_factor
+    s = size // (lr_factor or TASKS[task]["factor"])
     degraded = torch.rand(1, frames, 3, s, s, generator=g)
-    init = F.interpolate(degraded[0], (size, size), mode="area").clamp(0, 1)[None]
+    if "bicubic" in task:
+        init = F.interpolate(degraded[0], (size, size), mode="bicubic", align_corners=False).clamp(0, 1)[None]
+    else:
+        init = F.interpolate(degraded[0], (size, size), mode="area").clamp(0, 1)[None]
     degraded_n = (degraded - 0.5) / 0.5
     init_n = (init - 0.5) / 0.5
     rnn = F.interpolate(degraded_n[0], (size, size), mode="bicubic", align_corners=False).clamp(-1, 1)[None]
@@ -61,3 +67,47 @@ def diffusion_for(steps, learn_sigma=True):
 
 def identity_aux(x0, t, xt):
     return x0
+
+
+# ------------------------------------------------------------------ bicubic tasks (sr3.UNet)
+def sr3_config(image_size, use_fp16=True):
+    """MODEL_CONFIG['x8_bicubic'] of scripts/video_sample.py:78-96 at clip side `image_size`
+    (attention / BasicVSR++ resolutions scale with it: SURVEY.md section 8d)."""
+    return dict(image_size=image_size, in_channel=6, out_channel=3, inner_channel=64, norm_groups=16,
+                channel_mults=(1, 2, 4, 8, 16), attn_res=(image_size // 8, image_size // 16),
+                vsrpp_res=(image_size, image_size // 2), spatial_attn=False, temporal_attn=True, res_blocks=1,
+                dropout=0.0, dtype=torch.bfloat16 if use_fp16 else torch.float32, cross_frame_module=True,
+                use_checkpoint=True, num_frames=7, head_dim=64)
+
+
+def bicubic_diffusion_for(steps):
+    from .guided_diffusion.script_util import create_gaussian_diffusion
+    return create_gaussian_diffusion(diffusion_steps=2000, learn_sigma=False, noise_schedule="face_bicubic",
+                                     timestep_respacing=str(steps))
+
+
+def bicubic_taps(factor, a=-0.5):
+    """The 4*factor-tap bicubic kernel scripts/video_sample.py:205-226 hands to SRConv."""
+    def k(x):
+        x = abs(x)
+        if x <= 1:
+            return (a + 2) * x ** 3 - (a + 3) * x ** 2 + 1
+        if x < 2:
+            return a * x ** 3 - 5 * a * x ** 2 + 8 * a * x - 4 * a
+        return 0.0
+    n = factor * 4
+    taps = np.array([k((1 / factor) * (i - np.floor(n / 2) + 0.5)) for i in range(n)])
+    taps = taps / taps.sum()
+    t = torch.from_numpy(taps).float()
+    return t / t.sum()
+
+
+def face_weight_map(frames, size, inside):
+    """Stand-in for the face-parsing mask of scripts/video_sample.py:427-444: an ellipse of
+    background (mask=1 -> weight `inside`... the script weights background pixels) per frame."""
+    ys = torch.linspace(-1, 1, size).view(size, 1)
+    xs = torch.linspace(-1, 1, size).view(1, size)
+    face = ((xs / 0.55) ** 2 + (ys / 0.75) ** 2 <= 1).float()
+    background = 1 - face
+    w = background * inside + (1 - background) * 1.0
+    return w.view(1, 1, 1, size, size).repeat(1, frames, 1, 1, 1)
