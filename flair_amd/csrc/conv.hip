@@ -20,6 +20,8 @@
 // (chunk ^= (row>>2)&3) that makes every ds_read_b128 fragment read conflict-free.
 // Global loads for step k+1 are issued before the MFMAs of step k and written to the
 // other LDS buffer afterwards (one barrier per step).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -49,6 +51,7 @@ struct ConvArgs {
     int splitK;
     const float* fbias;    // optional per-(frame, channel) bias [T][fbiasLd] (emb added to h)
     int fbiasLd;
+    int debug;             // timing experiments only (FLAIR_CONV_DEBUG): 1 skip MFMA, 2 skip reloads
     int stride;            // spatial stride (1 or 2; im2col path only)
     int Hin, Win;          // input frame size (== H, W when stride == 1); H, W, P describe the OUTPUT
 };
@@ -290,6 +293,7 @@ void conv3x3_halo_kernel(ConvArgs a) {
     // software pipeline: chunk kk is multiplied out of LDS while chunks kk+1 .. kk+PF are in
     // flight in registers (set kk % PF holds chunk kk until it has been written to LDS)
     int issued = 0;
+    if (a.debug == 3) return;
 #pragma unroll
     for (int s_ = 0; s_ < PF; ++s_)
         if (issued < nch) {
@@ -299,17 +303,18 @@ void conv3x3_halo_kernel(ConvArgs a) {
         }
     write_lds(hreg[0], wreg[0]);
     __syncthreads();
+    if (a.debug == 4) return;
     for (int k = 0; k < nch; k += PF) {
 #pragma unroll
         for (int par = 0; par < PF; ++par) {
             const int kk = k + par;
             if (kk < nch) {
                 if (issued < nch) {       // set `par` went to LDS already: refill it
-                    issue(hreg[par], wreg[par]);
+                    if (a.debug != 2) issue(hreg[par], wreg[par]);
                     advance();
                     ++issued;
                 }
-                compute();
+                if (a.debug != 1) compute();
                 if (kk + 1 < nch) {
                     __syncthreads();      // everyone is done reading the staged chunk
                     write_lds(hreg[(par + 1) % PF], wreg[(par + 1) % PF]);
@@ -319,6 +324,78 @@ void conv3x3_halo_kernel(ConvArgs a) {
         }
     }
 
+    if (a.debug == 5) return;
+    // ---- epilogue.  The accumulator layout gives each lane 4 channels of one pixel (8-byte
+    // pieces scattered over 32 pixels per store).  Transpose each wave's 32 x 64 tile through LDS
+    // (staged as f32, so bias / activation / residuals stay exact) and let consecutive lanes
+    // write consecutive 16-byte pieces: whole 128-byte lines, vectorised residual loads.
+    if ((a.Cout & 7) == 0) {
+        constexpr int VEC = ET<E>::VEC;
+        constexpr int CHUNKS = 64 / VEC;                        // 16-byte output pieces per pixel
+        __syncthreads();                                        // LDS is free: all MFMA reads are done
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) {
+            char* tile = smem + (wave * RPW + j) * 32 * (64 * 4 + 16);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(tile + lr * (64 * 4 + 16) + (i * 32 + 8 * g + 4 * lh) * 4) =
+                        make_float4(acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2],
+                                    acc[j][i][4 * g + 3]);
+        }
+        __syncthreads();
+        constexpr int FPITCH = 64 * 4 + 16;                     // f32 staging pitch (both dtypes)
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) {
+            const int h = h0 + wave * RPW + j;
+            if (h >= a.H) continue;
+            const char* tile = smem + (wave * RPW + j) * 32 * FPITCH;
+            const long prow = ((long)t * a.H + h) * a.W + w0;
+#pragma unroll
+            for (int it = 0; it < 32 * CHUNKS / 64; ++it) {
+                const int id = it * 64 + lane;
+                const int px = id / CHUNKS, ch = id % CHUNKS;
+                const int co = co0 + ch * VEC;
+                if (co >= a.Cout) continue;
+                const long p = prow + px;
+                float v[VEC];
+                const float* src = reinterpret_cast<const float*>(tile + px * FPITCH) + ch * VEC;
+#pragma unroll
+                for (int e = 0; e < VEC; e += 4) {
+                    const float4 q = *reinterpret_cast<const float4*>(src + e);
+                    v[e] = q.x; v[e + 1] = q.y; v[e + 2] = q.z; v[e + 3] = q.w;
+                }
+                if (a.bias) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) v[e] += a.bias[co + e];
+                }
+                if (a.fbias) {
+                    const float* fb = a.fbias + (long)t * a.fbiasLd + co;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) v[e] += fb[e];
+                }
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[e] = apply_act(v[e], a.act);
+                if (a.res0) {
+                    float r[VEC];
+                    Vec16<E>::load(reinterpret_cast<const E*>(a.res0) + p * a.res0Ld + co, r);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) v[e] += r[e];
+                }
+                if (a.res1) {
+                    float r[VEC];
+                    Vec16<E>::load(reinterpret_cast<const E*>(a.res1) + p * a.res1Ld + co, r);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) v[e] += r[e];
+                }
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[e] *= a.outScale;
+                Vec16<E>::store(reinterpret_cast<E*>(a.y) + p * a.yLd + co, v);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < RPW; ++j) {
         const int h = h0 + wave * RPW + j, w = w0 + lr;
@@ -699,6 +776,10 @@ extern "C" int flair_conv_nhwc(const flair_conv_params* p, const void* const* x,
     FLAIR_CHECK(a.stride == 1 || a.stride == 2, "flair_conv_nhwc: stride %d unsupported", p->stride);
     a.part = nullptr;
     a.splitK = 1;
+    {
+        static const int dbg = getenv("FLAIR_CONV_DEBUG") ? atoi(getenv("FLAIR_CONV_DEBUG")) : 0;
+        a.debug = dbg;
+    }
     if (workspace && workspace_bytes >= flair_conv_workspace_bytes(p) && flair_conv_workspace_bytes(p) > 0) {
         FLAIR_CHECK(((uintptr_t)workspace) % 16 == 0, "flair_conv_nhwc: workspace alignment");
         a.part = reinterpret_cast<float*>(workspace);
