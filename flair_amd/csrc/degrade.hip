@@ -21,9 +21,18 @@
 
 namespace {
 
+__device__ __forceinline__ int pad_index(int a, int n, int reflect) {
+    if (reflect) {   // F.pad(mode="reflect"): -1 -> 1, n -> n-2
+        a = a < 0 ? -a : a;
+        a = a > n - 1 ? 2 * (n - 1) - a : a;
+        return a < 0 ? 0 : a;
+    }
+    return a < 0 ? 0 : (a > n - 1 ? n - 1 : a);
+}
+
 __global__ void depthwise_filter_kernel(const float* x, int planes, int Hin, int Win, const float* K, int kh, int kw,
                                         int pad, int so, int off, int stuff, int stuffOff, int Hout, int Wout,
-                                        float* y) {
+                                        int reflect, float* y) {
     extern __shared__ float ks[];
     for (int i = threadIdx.x; i < kh * kw; i += blockDim.x) ks[i] = K[i];
     __syncthreads();
@@ -36,13 +45,11 @@ __global__ void depthwise_filter_kernel(const float* x, int planes, int Hin, int
         const float* xp = x + pl * Hin * Win;
         float acc = 0.f;
         for (int u = 0; u < kh; ++u) {
-            int a = i * so + off + u - pad;
-            a = a < 0 ? 0 : (a > Hv - 1 ? Hv - 1 : a);
+            const int a = pad_index(i * so + off + u - pad, Hv, reflect);
             if (stuff > 1 && (a % stuff) != stuffOff) continue;
             const float* row = xp + (long)(a / stuff) * Win;
             for (int v = 0; v < kw; ++v) {
-                int b = j * so + off + v - pad;
-                b = b < 0 ? 0 : (b > Wv - 1 ? Wv - 1 : b);
+                const int b = pad_index(j * so + off + v - pad, Wv, reflect);
                 if (stuff > 1 && (b % stuff) != stuffOff) continue;
                 acc = fmaf(ks[u * kw + v], row[b / stuff], acc);
             }
@@ -195,14 +202,14 @@ inline int grid_for(long n) {
 
 extern "C" int flair_depthwise_filter(const float* x, int planes, int Hin, int Win, const float* filt, int kh, int kw,
                                       int pad, int out_stride, int out_offset, int stuff, int stuff_offset, int Hout,
-                                      int Wout, float* y, hipStream_t stream) {
+                                      int Wout, int reflect, float* y, hipStream_t stream) {
     FLAIR_CHECK(x && filt && y && planes > 0 && Hin > 0 && Win > 0 && kh > 0 && kw > 0 && kh * kw <= 4096,
                 "flair_depthwise_filter: bad argument");
     FLAIR_CHECK(out_stride >= 1 && stuff >= 1 && stuff_offset >= 0 && stuff_offset < stuff && Hout > 0 && Wout > 0,
                 "flair_depthwise_filter: bad sampling parameters");
     hipLaunchKernelGGL(depthwise_filter_kernel, dim3(grid_for((long)planes * Hout * Wout)), dim3(256),
                        (size_t)kh * kw * sizeof(float), stream, x, planes, Hin, Win, filt, kh, kw, pad, out_stride,
-                       out_offset, stuff, stuff_offset, Hout, Wout, y);
+                       out_offset, stuff, stuff_offset, Hout, Wout, reflect, y);
     FLAIR_LAUNCH_CHECK();
     return FLAIR_OK;
 }

@@ -223,5 +223,13 @@ class pseudoSR_PyTorch:
     def A(self, HR, scale_factor=1.0, use_zero_padding=False, kk=None):
         """pseudoSR.py:283-295 -> imresize_efficient (imresize_pseudoSR.py:163-178): reflect-pad,
         correlate with rot180(ds_kernel), keep [pre::1/scale]."""
-        raise NotImplementedError("flair_amd: pseudoSR.A (reflect-padded forward blur) is not on the "
-                                  "sampling path (only A_pinv is, video_sample.py:183-193)")
+        if scale_factor != 1.0 or use_zero_padding:
+            raise NotImplementedError("flair_amd: pseudoSR.A supports the default arguments only")
+        k = self._dev["down"]                      # rot180(ds_kernel), the cross-correlation mask
+        f = self.ds_factor
+        HR = HR.float().contiguous()
+        H, W = HR.shape[-2:]
+        # NB: with scale_factor=1.0 the reference keeps EVERY filtered sample ([pre::1]); the blur
+        # is applied but no decimation happens (imresize_pseudoSR.py:178).
+        return ops.depthwise_filter(HR, k, pad=k.shape[0] // 2, out_stride=1, out_offset=0, reflect=True,
+                                    out_hw=(H, W))[:, :, int(self.pre_stride[0]):, int(self.pre_stride[1]):]

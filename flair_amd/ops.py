@@ -443,14 +443,16 @@ def learned_range_variance(model_out, C, min_log, max_log):
 
 
 # ------------------------------------------------------------------- degradation ops
-def depthwise_filter(x, filt, *, pad, out_stride=1, out_offset=0, stuff=1, stuff_offset=0, out_hw=None):
+def depthwise_filter(x, filt, *, pad, out_stride=1, out_offset=0, stuff=1, stuff_offset=0, out_hw=None,
+                     reflect=False):
     """x: (N,C,H,W) f32; filt: (kh,kw) f32 device tensor shared by all planes."""
     N, C, H, W = x.shape
     assert x.dtype == torch.float32 and x.is_contiguous() and filt.dtype == torch.float32 and filt.is_contiguous()
     Ho, Wo = out_hw
     out = torch.empty((N, C, Ho, Wo), dtype=torch.float32, device=x.device)
     check(lib().flair_depthwise_filter(ptr(x), N * C, H, W, ptr(filt), filt.shape[0], filt.shape[1], pad,
-                                       out_stride, out_offset, stuff, stuff_offset, Ho, Wo, ptr(out), stream()),
+                                       out_stride, out_offset, stuff, stuff_offset, Ho, Wo, int(reflect), ptr(out),
+                                       stream()),
           "flair_depthwise_filter")
     return out
 

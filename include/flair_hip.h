@@ -277,10 +277,13 @@ int flair_dcn_align(const flair_dcn_params* p, const void* x0, const void* x1, c
  *   out[i][j] = sum_{u,v} K[u][v] * IN(i*out_stride + out_offset + u - pad, j*... + v - pad)
  * where IN clamps to the virtual image of size (Hin*stuff, Win*stuff) whose samples are zero
  * except at coordinates == stuff_offset (mod stuff) (zero-stuffing up-sampler).
- *   Down  : pad 4, out_stride 4, out_offset pre_stride;  InvHtH: pad 19;  Up: stuff 4. */
+ *   Down  : pad 4, out_stride 4, out_offset pre_stride;  InvHtH: pad 19;  Up: stuff 4.
+ * reflect != 0 uses F.pad(mode="reflect") instead of replication (imresize_efficient, the
+ * forward operator A: imresize_pseudoSR.py:163-178). */
 int flair_depthwise_filter(const float* x, int planes, int Hin, int Win, const float* filt, int kh,
                            int kw, int pad, int out_stride, int out_offset, int stuff,
-                           int stuff_offset, int Hout, int Wout, float* y, hipStream_t stream);
+                           int stuff_offset, int Hout, int Wout, int reflect, float* y,
+                           hipStream_t stream);
 /* jpeg_decode(jpeg_encode(x, qf), qf) of jpeg.py:72-167 on (N,3,S,S) images in [-1,1].
  * q_luma, q_chroma, dct8 are HOST arrays of 64 floats (quantisation tables of
  * general_quant_matrix, jpeg.py:35-65, and the 8x8 orthonormal DCT-II matrix); workspace:

@@ -120,6 +120,14 @@ class BlurOperator:
         z[:, :, self.pre[0]::self.f, self.pre[1]::self.f] = x
         return self._filt(z, self.w_up)
 
+    def a_forward(self, x):
+        """pseudoSR_PyTorch.A with its default arguments (pseudoSR.py:283-295 ->
+        imresize_efficient, imresize_pseudoSR.py:163-178): reflect-pad, correlate with
+        rot180(ds_kernel), keep [pre::1] (scale_factor=1.0 -> no decimation)."""
+        p = self.w_down.shape[-1] // 2
+        y = F.conv2d(F.pad(x, (p, p, p, p), mode="reflect"), self.w_down, groups=3)
+        return y[:, :, self.pre[0]:, self.pre[1]:]
+
     def a_pinv(self, lr, x=None, codec=None):
         lr = lr[:, -3:]
         if x is None:

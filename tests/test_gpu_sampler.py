@@ -97,7 +97,8 @@ def test_blur_operator_vs_oracle(dev, size):
                            ("inv", A.Conv_LR_with_Inv_hTh_OP(lr.to(dev)), o.inv(lr)),
                            ("up", A.Upscale_OP(lr.to(dev)), o.up(lr)),
                            ("a_pinv", A.A_pinv(lr.to(dev), x.to(dev)), o.a_pinv(lr, x)),
-                           ("a_pinv_lr", A.A_pinv(lr.to(dev)), o.a_pinv(lr))]:
+                           ("a_pinv_lr", A.A_pinv(lr.to(dev)), o.a_pinv(lr)),
+                           ("a_forward", A.A(x.to(dev)), o.a_forward(x))]:
         err = (got.cpu() - ref).abs().max().item()
         assert err <= 2e-5 * max(1.0, ref.abs().max().item()), (name, err)
 

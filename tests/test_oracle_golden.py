@@ -152,6 +152,8 @@ def test_blur_filters_and_operator():
     assert np.abs(op.a_pinv(low).numpy() - g["a_pinv_lr_only"]).max() <= 2e-5
     codec = lambda v: od.jpeg_decode(od.jpeg_encode(v, 60), 60)    # noqa: E731
     assert np.abs(op.a_pinv(low, img, codec=codec).numpy() - g["a_pinv_jpeg60"]).max() <= 5e-5
+    f = load("g8_blur_forward")
+    assert np.abs(op.a_forward(torch.from_numpy(f["x"])).numpy() - f["y"]).max() <= 2e-6
 
 
 @pytest.mark.parametrize("qf", [10, 60, 90])
