@@ -8,14 +8,20 @@
 // modulated_deformable_im2col_gpu_kernel + addmm (dcn/src/deform_conv_cuda_kernel.cu:571-633,
 // dcn/src/deform_conv_cuda.cpp:540-560).
 //
-//   raw  : [F][H][W][rawLd]  conv_offset output, 27*G channels: o1 | o2 | mask
-//   dy,dx(g,k) = M*tanh(raw[2*(g*9+k)+{0,1}]) + flow_g.{y,x};  flow_g = flow1 (g < G/2) else flow2
-//   m(g,k)     = sigmoid(raw[18*G + g*9 + k])
+//   raw  : [F][H][W][rawLd]  conv_offset output, 27*G channels in TAP-MAJOR order (the host
+//          permutes the output channels of the last conv_offset convolution when it packs
+//          its weights, which is free):
+//            raw[2*(k*G+g)+{0,1}] = (dy,dx) pre-activation of group g, tap k
+//            raw[18*G + k*G + g]  = mask pre-activation
+//          (reference order: 2*(g*9+k)+{0,1} and 18*G + g*9 + k)
+//   dy,dx(g,k) = M*tanh(raw..) + flow_g.{y,x};  flow_g = flow1 (g < G/2) else flow2
+//   m(g,k)     = sigmoid(raw..)
 //   Y[p][co]   = bias[co] + sum_{k,ci} Wt[co][k][ci] * m(g(ci),k) * bilinear(X[ci], p + pk + d(g(ci),k))
 //
-// Same MFMA tiling as conv.hip (weights = A operand, gathered pixels = B operand, 64-byte
-// swizzled LDS rows); the activation staging is replaced by a 4-corner NHWC gather of
+// Same MFMA operand roles as conv.hip (weights = A operand, gathered pixels = B operand,
+// XOR-swizzled LDS rows); the activation staging is replaced by a 4-corner NHWC gather of
 // 16-byte channel chunks (one deformable group = 8 or 16 contiguous channels).
+
 #include "common.h"
 
 namespace {
@@ -38,7 +44,6 @@ struct DcnArgs {
 
 template <typename E> struct MmaD;
 template <> struct MmaD<bf16_t> {
-    static constexpr int BKE = 32;
     static __device__ __forceinline__ int chunk(int i, int half) { return 2 * i + half; }
     static __device__ __forceinline__ void run(const uint4 (&a)[2], const uint4 (&b)[2], f32x16& acc) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[0]),
@@ -48,7 +53,6 @@ template <> struct MmaD<bf16_t> {
     }
 };
 template <> struct MmaD<float> {
-    static constexpr int BKE = 16;
     static __device__ __forceinline__ int chunk(int i, int half) { return 2 * half + i; }
     static __device__ __forceinline__ void run(const uint4 (&a)[2], const uint4 (&b)[2], f32x16& acc) {
         const float* af = reinterpret_cast<const float*>(a);
@@ -58,7 +62,14 @@ template <> struct MmaD<float> {
     }
 };
 
-__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+// LDS tile rows hold one K step (CPR 16-byte chunks) of one cout / pixel; the chunk index is
+// XORed with a row-derived value so that 16 consecutive rows read the same logical chunk from
+// 16 different bank groups (conflict-free ds_read_b128) for 64/128/256-byte rows.
+template <int CPR>
+__device__ __forceinline__ int tile_off(int row, int chunk) {
+    const int s = CPR == 4 ? (row >> 2) & 3 : CPR == 8 ? (row >> 1) & 7 : row & 15;
+    return row * (CPR * 16) + ((chunk ^ s) << 4);
+}
 
 __device__ __forceinline__ float fast_tanh(float x) {
     // 1 - 2/(e^{2x}+1); |err| ~ 1e-7 relative, saturates cleanly for large |x|
@@ -66,32 +77,41 @@ __device__ __forceinline__ float fast_tanh(float x) {
     return 1.f - 2.f / (e + 1.f);
 }
 
-// Workgroup = 64 consecutive pixels of one frame x ALL output channels (NCF fragments of 32),
-// so every bilinear gather is done exactly once.  The conv_offset output of the 64 pixels
-// (27*G channels) is staged in LDS once; per K step (one tap, 64 bytes of channels) every
-// thread owns one (pixel, 16-byte channel chunk): it turns the staged raw offsets into 4
-// corner addresses and issues 4 unconditional buffer loads (out-of-range corners read 0)
-// plus its share of the weight tile.  Two register sets alternate, so the loads of step k+1
-// are in flight while step k is blended, written to LDS and multiplied on the matrix cores.
-template <typename E, int NCF>
-__global__ __launch_bounds__(256) void dcn_kernel(DcnArgs a) {
-    constexpr int BKE = MmaD<E>::BKE;
+// Workgroup = TP = 32*NPF consecutive pixels of one frame x ALL output channels (NCF
+// fragments of 32), so every bilinear gather is done exactly once; TPP threads share one
+// pixel, each owning one 16-byte channel chunk of the K step (one tap, TPP*16 bytes of
+// channels).  A per-frame call only has H*W*TPP threads of gather parallelism, so the tile
+// shapes are picked to keep >= 2048 waves in flight at 256^2 / 128^2 while the weight tile
+// (re-read by every workgroup) is amortised over as many pixels as possible.
+//
+// Per tap, the 3*G raw offset/mask values of the TP pixels are staged in LDS (double
+// buffered, fetched one tap ahead).  Per K step every thread turns its group's staged values
+// into 4 corner addresses and issues 4 unconditional buffer loads (out-of-range corners read
+// 0) plus its share of the weight tile.  Two register sets alternate, so the loads of step
+// k+1 are in flight while step k is blended, written to LDS and multiplied on the matrix cores.
+template <typename E, int NCF, int NPF, int TPP>
+__global__ __launch_bounds__(32 * NPF * TPP, (NCF >= 4 ? 32 * NPF * TPP / 256 : 4)) void dcn_kernel(DcnArgs a) {
+    constexpr int NT = 32 * NPF * TPP, NW = NT / 64;
+    constexpr int TP = 32 * NPF, TC = 32 * NCF, CPR = TPP;
     constexpr int VEC = ET<E>::VEC;
     constexpr unsigned ESZ = sizeof(E);
-    constexpr int TC = NCF * 32, TP = 64;
-    constexpr int WR = TC / 64 > 0 ? TC / 64 : 1;             // weight pieces per thread
-    constexpr int PAIRS = NCF / 2;                            // (cout-frag, pixel-frag) pairs per wave
+    constexpr int BKE = CPR * VEC;                            // K elements per step
+    constexpr int PAIRS = NCF * NPF / NW;                     // (cout-frag, pixel-frag) pairs per wave
+    static_assert(PAIRS * NW == NCF * NPF && PAIRS >= 1, "tile shape");
+    constexpr int WR = (TC * CPR + NT - 1) / NT;              // weight pieces per thread
+    constexpr int RAWR = (TP * 3 * (int)ESZ + NT - 1) / NT;   // raw pieces per thread and tap (G <= 16)
+    constexpr int BUF = (TC + TP) * CPR * 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int rawC = 27 * a.G;
-    const int rawPitch = ((rawC * (int)ESZ + 15) / 16) * 16 + 16;   // +16 B: spreads pixels over banks
+    const int G = a.G;
+    const int slabPieces = 3 * G * (int)ESZ / 16, offPieces = 2 * G * (int)ESZ / 16;
+    const int rawPitch = 3 * G * (int)ESZ + 16;               // +16 B: spreads pixels over banks
     char* sraw = smem;
-    char* stile = smem + TP * rawPitch;
-    constexpr int BUF = (TC + TP) * 64;
+    char* stile = smem + 2 * TP * rawPitch;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 31, lh = lane >> 5;
     const long p0 = (long)blockIdx.x * TP;
-    const int q = tid & 3, srow = tid >> 2;
+    const int q = tid % TPP, srow = tid / TPP;
     long p = p0 + srow;
     const bool pvalid = p < a.P;
     if (!pvalid) p = a.P - 1;
@@ -102,23 +122,34 @@ __global__ __launch_bounds__(256) void dcn_kernel(DcnArgs a) {
     if (a.flow1) fl1 = *reinterpret_cast<const float2*>(a.flow1 + p * 2);
     if (a.flow2) fl2 = *reinterpret_cast<const float2*>(a.flow2 + p * 2);
 
-    // ---- stage the raw conv_offset rows of the 64 pixels (16-byte pieces, coalesced)
-    {
-        const int piecesPerPix = (rawC * (int)ESZ + 15) / 16;
-        const __amdgpu_buffer_rsrc_t rr = make_rsrc(a.raw, a.rawBytes);
-        for (int id = tid; id < TP * piecesPerPix; id += 256) {
-            const int px = id / piecesPerPix, pc = id % piecesPerPix;
+    // ---- per-tap staging of the raw conv_offset values.  Runs in the post-barrier (MFMA)
+    // phase of a K step, where the consumed gather registers are dead, so it adds nothing to
+    // the register peak; the mapping is recomputed per tap (once every cbPerTap steps).
+    const __amdgpu_buffer_rsrc_t rr = make_rsrc(a.raw, a.rawBytes);
+    auto stage_raw = [&](int tap) {
+        uint4 reg[RAWR];
+        int dst[RAWR];
+#pragma unroll
+        for (int j = 0; j < RAWR; ++j) {
+            const int id = tid + j * NT;
+            const int px = id / slabPieces, pc = id - px * slabPieces;
             const long pp = p0 + px;
-            const unsigned off = pp < a.P ? (unsigned)(pp * a.rawLd * ESZ) + pc * 16 : FLAIR_OOB;
-            *reinterpret_cast<uint4*>(sraw + px * rawPitch + pc * 16) = buf_load16(rr, off);
+            const bool isOff = pc < offPieces;
+            const unsigned within = isOff ? (unsigned)(2 * tap * G) * ESZ + pc * 16
+                                          : (unsigned)(18 * G + tap * G) * ESZ + (pc - offPieces) * 16;
+            reg[j] = buf_load16(rr, px < TP && pp < a.P ? (unsigned)(pp * a.rawLd * ESZ) + within : FLAIR_OOB);
+            dst[j] = px < TP ? ((tap & 1) * TP + px) * rawPitch + pc * 16 : -1;
         }
-    }
-    __syncthreads();
-    const E* myraw = reinterpret_cast<const E*>(sraw + srow * rawPitch);
+#pragma unroll
+        for (int j = 0; j < RAWR; ++j)
+            if (dst[j] >= 0) *reinterpret_cast<uint4*>(sraw + dst[j]) = reg[j];
+    };
 
-    const int cpg = a.Cin / a.G;
+    const int cpg = a.Cin / G;
+    int cpgShift = 0;                       // cpg is a power of two (8 or 16 channels per group)
+    while ((1 << cpgShift) < cpg) ++cpgShift;
     const int halfC = a.Cin / 2;
-    const int cbPerTap = a.Cin / BKE;
+    const int cbPerTap = a.Cin / BKE;       // even: both input halves are multiples of BKE
     const int nk = 9 * cbPerTap;
     const __amdgpu_buffer_rsrc_t xr0 = make_rsrc(a.x[0], a.xBytes[0]);
     const __amdgpu_buffer_rsrc_t xr1 = make_rsrc(a.x[1], a.xBytes[1]);
@@ -131,16 +162,17 @@ __global__ __launch_bounds__(256) void dcn_kernel(DcnArgs a) {
         float wt[4];
     } rs[2];
 
-    auto issue = [&](Regs& r, int k) {
-        const int tap = k / cbPerTap, cb = k % cbPerTap;
+    int itap = 0, icb = 0, ikh = 0, ikw = 0;   // K-loop position of the NEXT issue (block uniform)
+    auto issue = [&](Regs& r) {
+        const int tap = itap, cb = icb;
         const int c = cb * BKE + q * VEC;
-        const int g = c / cpg;
-        const int o = g * 9 + tap;
-        const float ry = ET<E>::ld(myraw + 2 * o), rx = ET<E>::ld(myraw + 2 * o + 1);
-        const float rm = ET<E>::ld(myraw + 18 * a.G + o);
-        const float2 fl = g < a.G / 2 ? fl1 : fl2;
-        const float sy = (float)(ph - 1 + tap / 3) + a.maxMag * fast_tanh(ry) + fl.y;
-        const float sx = (float)(pw - 1 + tap % 3) + a.maxMag * fast_tanh(rx) + fl.x;
+        const int g = c >> cpgShift;
+        const E* myraw = reinterpret_cast<const E*>(sraw + ((tap & 1) * TP + srow) * rawPitch);
+        const float ry = ET<E>::ld(myraw + 2 * g), rx = ET<E>::ld(myraw + 2 * g + 1);
+        const float rm = ET<E>::ld(myraw + 2 * G + g);
+        const float2 fl = g < G / 2 ? fl1 : fl2;
+        const float sy = (float)(ph - 1 + ikh) + a.maxMag * fast_tanh(ry) + fl.y;
+        const float sx = (float)(pw - 1 + ikw) + a.maxMag * fast_tanh(rx) + fl.x;
         const float mk = 1.f / (1.f + __expf(-rm));
         const float fy = floorf(sy), fx = floorf(sx);
         const float ay = sy - fy, ax = sx - fx;
@@ -162,8 +194,18 @@ __global__ __launch_bounds__(256) void dcn_kernel(DcnArgs a) {
         }
 #pragma unroll
         for (int j = 0; j < WR; ++j) {
-            const int n = srow + 64 * j;
-            r.w[j] = buf_load16(wrs, n < a.Cout && n < TC ? (unsigned)((n * 9 + tap) * a.Cin + c) * ESZ : FLAIR_OOB);
+            const int id = tid + j * NT;
+            const int n = id / CPR, ch = id % CPR;
+            r.w[j] = buf_load16(wrs, n < a.Cout && n < TC ? (unsigned)((n * 9 + tap) * a.Cin + cb * BKE + ch * VEC) * ESZ
+                                                          : FLAIR_OOB);
+        }
+        if (++icb == cbPerTap) {
+            icb = 0;
+            ++itap;
+            if (++ikw == 3) {
+                ikw = 0;
+                ++ikh;
+            }
         }
     };
     auto blend_and_stage = [&](const Regs& r, int buf) {
@@ -180,10 +222,12 @@ __global__ __launch_bounds__(256) void dcn_kernel(DcnArgs a) {
         char* base = stile + buf * BUF;
         alignas(16) E out[VEC];
         Vec16<E>::store(out, acc);
-        *reinterpret_cast<uint4*>(base + TC * 64 + lds_off(srow, q)) = *reinterpret_cast<const uint4*>(out);
+        *reinterpret_cast<uint4*>(base + TC * CPR * 16 + tile_off<CPR>(srow, q)) = *reinterpret_cast<const uint4*>(out);
 #pragma unroll
-        for (int j = 0; j < WR; ++j)
-            if (srow + 64 * j < TC) *reinterpret_cast<uint4*>(base + lds_off(srow + 64 * j, q)) = r.w[j];
+        for (int j = 0; j < WR; ++j) {
+            const int id = tid + j * NT;
+            if (id < TC * CPR) *reinterpret_cast<uint4*>(base + tile_off<CPR>(id / CPR, id % CPR)) = r.w[j];
+        }
     };
 
     f32x16 acc[PAIRS];
@@ -191,39 +235,60 @@ __global__ __launch_bounds__(256) void dcn_kernel(DcnArgs a) {
     for (int i = 0; i < PAIRS; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    const int pfrag = wave & 1;               // which 32-pixel half this wave multiplies
-    const int cf0 = (wave >> 1) * PAIRS;      // first cout fragment of this wave
 
-    issue(rs[0], 0);
+    // Tap T's raw values are staged in the post-barrier phase of step T*cbPerTap - 3: after
+    // the last reader of that LDS buffer (tap T-2, top of step (T-1)*cbPerTap - 1) and with one
+    // barrier to go before their first reader (top of step T*cbPerTap - 1).
+    stage_raw(0);
+    int stageTap = 1;
+    if (cbPerTap < 3) {
+        stage_raw(1);
+        stageTap = 2;
+    }
+    int stageAt = stageTap * cbPerTap - 3;
+    __syncthreads();
+    issue(rs[0]);
     for (int k = 0; k < nk; k += 2) {
 #pragma unroll
         for (int par = 0; par < 2; ++par) {
-            const int kk = k + par;
-            if (kk + 1 < nk) issue(rs[par ^ 1], kk + 1);
+            if (k + par + 1 < nk) issue(rs[par ^ 1]);
             blend_and_stage(rs[par], par);
             __syncthreads();
             const char* wb = stile + par * BUF;
-            const char* xb = wb + TC * 64;
-            uint4 bf[2];
-            bf[0] = *reinterpret_cast<const uint4*>(xb + lds_off(pfrag * 32 + lr, MmaD<E>::chunk(0, lh)));
-            bf[1] = *reinterpret_cast<const uint4*>(xb + lds_off(pfrag * 32 + lr, MmaD<E>::chunk(1, lh)));
+            const char* xb = wb + TC * CPR * 16;
 #pragma unroll
             for (int i = 0; i < PAIRS; ++i) {
-                uint4 af[2];
-                af[0] = *reinterpret_cast<const uint4*>(wb + lds_off((cf0 + i) * 32 + lr, MmaD<E>::chunk(0, lh)));
-                af[1] = *reinterpret_cast<const uint4*>(wb + lds_off((cf0 + i) * 32 + lr, MmaD<E>::chunk(1, lh)));
-                MmaD<E>::run(af, bf, acc[i]);
+                const int pair = wave * PAIRS + i;
+                const int pfrag = pair % NPF, cf = pair / NPF;
+#pragma unroll
+                for (int ks = 0; ks < CPR / 4; ++ks) {
+                    uint4 af[2], bf[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int ch = ks * 4 + MmaD<E>::chunk(h, lh);
+                        bf[h] = *reinterpret_cast<const uint4*>(xb + tile_off<CPR>(pfrag * 32 + lr, ch));
+                        af[h] = *reinterpret_cast<const uint4*>(wb + tile_off<CPR>(cf * 32 + lr, ch));
+                    }
+                    MmaD<E>::run(af, bf, acc[i]);
+                }
+            }
+            if (k + par == stageAt && stageTap < 9) {
+                stage_raw(stageTap);
+                ++stageTap;
+                stageAt += cbPerTap;
             }
         }
     }
-    const long po = p0 + pfrag * 32 + lr;
-    if (po >= a.P) return;
     E* y = reinterpret_cast<E*>(a.y);
 #pragma unroll
-    for (int i = 0; i < PAIRS; ++i)
+    for (int i = 0; i < PAIRS; ++i) {
+        const int pair = wave * PAIRS + i;
+        const int pfrag = pair % NPF, cf = pair / NPF;
+        const long po = p0 + pfrag * 32 + lr;
+        if (po >= a.P) continue;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int co = (cf0 + i) * 32 + 8 * g + 4 * lh;
+            const int co = cf * 32 + 8 * g + 4 * lh;
             if (co >= a.Cout) continue;
             float v[4];
 #pragma unroll
@@ -238,16 +303,24 @@ __global__ __launch_bounds__(256) void dcn_kernel(DcnArgs a) {
                 *reinterpret_cast<uint2*>(dst) = pk;
             }
         }
+    }
 }
 
 }  // namespace
 
-template <typename E, int NCF>
+template <typename E, int NCF, int NPF, int TPP>
 static int launch_dcn(const DcnArgs& a, hipStream_t stream) {
-    const int esz = (int)sizeof(E);
-    const int rawPitch = ((27 * a.G * esz + 15) / 16) * 16 + 16;
-    const size_t lds = (size_t)64 * rawPitch + 2 * (NCF * 32 + 64) * 64;
-    hipLaunchKernelGGL((dcn_kernel<E, NCF>), dim3(cdiv(a.P, 64)), dim3(256), lds, stream, a);
+    constexpr int NT = 32 * NPF * TPP, TP = 32 * NPF, TC = 32 * NCF;
+    const int rawPitch = 3 * a.G * (int)sizeof(E) + 16;
+    const size_t lds = (size_t)2 * TP * rawPitch + 2 * (TC + TP) * TPP * 16;
+    static bool attr = false;
+    if (!attr) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_kernel<E, NCF, NPF, TPP>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        FLAIR_CHECK(e == hipSuccess, "flair_dcn_align: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr = true;
+    }
+    hipLaunchKernelGGL((dcn_kernel<E, NCF, NPF, TPP>), dim3(cdiv(a.P, TP)), dim3(NT), lds, stream, a);
     FLAIR_LAUNCH_CHECK();
     return FLAIR_OK;
 }
@@ -257,10 +330,12 @@ extern "C" int flair_dcn_align(const flair_dcn_params* p, const void* x0, const 
                                hipStream_t stream) {
     FLAIR_CHECK(p && x0 && x1 && raw && w && y, "flair_dcn_align: null argument");
     FLAIR_CHECK(p->dtype == FLAIR_F32 || p->dtype == FLAIR_BF16, "flair_dcn_align: bad dtype");
-    const int vec = p->dtype == FLAIR_BF16 ? 8 : 4, bke = p->dtype == FLAIR_BF16 ? 32 : 16;
+    const int vec = p->dtype == FLAIR_BF16 ? 8 : 4;
+    const int bke = vec * (p->Cout <= 64 ? 4 : 8);      // K elements per step of the chosen tile
     const int esz = p->dtype == FLAIR_BF16 ? 2 : 4;
-    FLAIR_CHECK(p->G > 0 && p->G % 2 == 0 && p->Cin % p->G == 0 && (p->Cin / p->G) % vec == 0 &&
-                    (p->Cin / 2) % bke == 0,
+    const int cpg = p->G > 0 ? p->Cin / p->G : 0;
+    FLAIR_CHECK(p->G > 0 && p->G % 8 == 0 && p->G <= 16 && p->Cin % p->G == 0 && cpg % vec == 0 &&
+                    (cpg & (cpg - 1)) == 0 && (p->Cin / 2) % bke == 0,
                 "flair_dcn_align: Cin=%d G=%d not supported", p->Cin, p->G);
     FLAIR_CHECK(p->Cout % 4 == 0 && p->Cout <= 128 && p->raw_ld >= 27 * p->G && (p->raw_ld * esz) % 16 == 0,
                 "flair_dcn_align: Cout (<=128) / raw_ld");
@@ -277,7 +352,9 @@ extern "C" int flair_dcn_align(const flair_dcn_params* p, const void* x0, const 
     FLAIR_CHECK(b0 < 0x80000000ull && b1 < 0x80000000ull && br < 0x80000000ull, "flair_dcn_align: tensor spans >= 2 GiB");
     a.xBytes[0] = (unsigned)b0; a.xBytes[1] = (unsigned)b1; a.rawBytes = (unsigned)((br + 15) / 16 * 16);
     a.wBytes = (unsigned)((unsigned long long)p->Cout * 9 * p->Cin * esz);
+    // Tile choice (measured on per-frame 256^2 / 128^2 calls, profiles/README.md): 64-pixel x 64-cout
+    // tiles with 4 threads per pixel for c=64, 32-pixel x 128-cout tiles with 8 threads per pixel above.
     if (p->dtype == FLAIR_BF16)
-        return p->Cout <= 64 ? launch_dcn<bf16_t, 2>(a, stream) : launch_dcn<bf16_t, 4>(a, stream);
-    return p->Cout <= 64 ? launch_dcn<float, 2>(a, stream) : launch_dcn<float, 4>(a, stream);
+        return p->Cout <= 64 ? launch_dcn<bf16_t, 2, 2, 4>(a, stream) : launch_dcn<bf16_t, 4, 1, 8>(a, stream);
+    return p->Cout <= 64 ? launch_dcn<float, 2, 2, 4>(a, stream) : launch_dcn<float, 4, 1, 8>(a, stream);
 }

@@ -315,11 +315,13 @@ class SecondOrderDeformableAlignment(nn.Module):
         c = self.out_channels
         ka = ops.k_align(dtype)
         co = self.conv_offset
+        perm = ops.dcn_raw_permutation(self.deform_groups)   # tap-major offsets for flair_dcn_align
+        w6, b6 = co[6].weight.detach()[perm], co[6].bias.detach()[perm]
         return dict(
             w0=_pack(co[0].weight, [(c, c), (c, c), (c, c), (4, ka)], dtype, device), b0=_dev(co[0].bias, device),
             w2=_pack(co[2].weight, [(c, c)], dtype, device), b2=_dev(co[2].bias, device),
             w4=_pack(co[4].weight, [(c, c)], dtype, device), b4=_dev(co[4].bias, device),
-            w6=_pack(co[6].weight, [(c, c)], dtype, device), b6=_dev(co[6].bias, device),
+            w6=_pack(w6, [(c, c)], dtype, device), b6=_dev(b6, device),
             wd=_pack(self.weight, [(2 * c, 2 * c)], dtype, device), bd=_dev(self.bias, device))
 
 

@@ -15,7 +15,7 @@ from ._lib import (ACT_LRELU01, ACT_NONE, ACT_RELU, ACT_SILU, ConvParams, check,
 
 __all__ = ["conv", "group_norm", "nchw_to_clip", "clip_to_nchw", "timestep_embedding", "linear",
            "qkv_attention", "temporal_attention", "flow_warp", "flow_compose", "resize",
-           "dcn_align", "scale_pixels", "predict_xstart", "sampler_update",
+           "dcn_align", "dcn_raw_permutation", "scale_pixels", "predict_xstart", "sampler_update",
            "ACT_NONE", "ACT_RELU", "ACT_LRELU01", "ACT_SILU"]
 
 
@@ -346,7 +346,23 @@ def resize(x, size, mode, *, channels=None, out=None, scale_c0=1.0, scale_c1=1.0
     return out
 
 
+def dcn_raw_permutation(groups):
+    """Index tensor taking the reference's conv_offset channel order (o1 | o2 | mask with
+    group-major (g*9+k) indexing, unet_new.py:877-885) to the tap-major order flair_dcn_align
+    reads: new[2*(k*G+g)+e] = old[2*(g*9+k)+e], new[18G + k*G + g] = old[18G + g*9 + k].
+    Applied to the OUTPUT channels of the last conv_offset convolution when it is packed."""
+    G = groups
+    perm = torch.empty(27 * G, dtype=torch.long)
+    for k in range(9):
+        for g in range(G):
+            for e in range(2):
+                perm[2 * (k * G + g) + e] = 2 * (g * 9 + k) + e
+            perm[18 * G + k * G + g] = 18 * G + g * 9 + k
+    return perm
+
+
 def dcn_align(x0, x1, raw, flow1, flow2, weight, bias, cout, *, groups=16, max_mag=10.0, out=None):
+    """raw: conv_offset output in TAP-MAJOR channel order (see dcn_raw_permutation)."""
     F_, H, W, ch = x0.shape
     p = DcnParams()
     p.dtype = dtype_code(x0)

@@ -204,12 +204,12 @@ def test_resize(dev, mode, size):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("c", [64, 128])
-def test_dcn(dev, dtype, c):
+@pytest.mark.parametrize("c,hw", [(64, (12, 10)), (128, (12, 10)), (64, (20, 27)), (128, (9, 23))])
+def test_dcn(dev, dtype, c, hw):
     from oracle.thirdparty import deform_conv2d
     ops = _ops()
     g = torch.Generator().manual_seed(21 + c)
-    H, W, G = 12, 10, 16
+    H, W, G = hw[0], hw[1], 16
     x = rb(torch.randn(1, 2 * c, H, W, generator=g), dtype)
     raw = rb(torch.randn(1, 27 * G, H, W, generator=g), dtype)
     f1 = torch.randn(1, H, W, 2, generator=g) * 2
@@ -223,8 +223,9 @@ def test_dcn(dev, dtype, c):
     off2 = off2 + f2.permute(0, 3, 1, 2).flip(1).repeat(1, off2.shape[1] // 2, 1, 1)
     ref = deform_conv2d(x, torch.cat([off1, off2], 1), w, b, (1, 1), (1, 1), (1, 1), torch.sigmoid(mask))
     wp = ops.pack_conv_weight(w, [(2 * c, 2 * c)], dtype).to(dev)
-    y = ops.dcn_align(to_clip(x[:, :c], dtype, dev), to_clip(x[:, c:], dtype, dev), to_clip(raw, dtype, dev),
-                      f1.to(dev), f2.to(dev), wp, b.to(dev), c)
+    raw_tap_major = raw[:, ops.dcn_raw_permutation(G)]     # the layout the fused kernel reads
+    y = ops.dcn_align(to_clip(x[:, :c], dtype, dev), to_clip(x[:, c:], dtype, dev),
+                      to_clip(raw_tap_major, dtype, dev), f1.to(dev), f2.to(dev), wp, b.to(dev), c)
     torch.cuda.synchronize()
     assert_close(from_clip(y), ref, dtype, f"dcn c={c}", scale=2.0)
 
