@@ -8,10 +8,13 @@
 // Statistics are joint over (C/groups) x frames_per_stat x H x W.  HBM-bound: three
 // launches per norm, two passes over the tensor:
 //   gn_partial  : every workgroup streams a pixel range with 16-byte loads, keeps
-//                 per-channel f32 sum / sum-of-squares in registers, folds the rows
-//                 of the workgroup through LDS and writes one partial per channel;
-//   gn_finalize : one wavefront per (stat, group) adds the partials in f64 with a
-//                 64-lane shuffle tree -> mean, rstd;
+//                 per-channel f32 sum / sum-of-squares in registers, folds the rows and
+//                 the channels of a group through LDS and writes one partial per group;
+//   gn_finalize : one wavefront per (stat, group) adds the partials in f64 (4 loads in
+//                 flight per lane, 64-lane shuffle tree) -> mean, rstd.  A separate launch
+//                 on purpose: folding it into gn_partial with a "last workgroup" ticket needs
+//                 a device-scope fence in every workgroup, which on the 8-XCD part writes
+//                 back / invalidates the L2 and cost 5x the whole statistics pass;
 //   gn_apply    : y = act(x*A + B) with A,B folded per (frame, channel) from
 //                 mean/rstd/gamma/beta/(scale,shift); optionally writes the 2x2
 //                 average-pooled or nearest-upsampled result and the resampled
@@ -27,9 +30,9 @@ struct GnSrc {
 };
 
 template <typename E>
-__global__ void gn_partial_kernel(GnSrc s, int C, long pixPerStat, int blocksPerStat, float* part) {
+__global__ void gn_partial_kernel(GnSrc s, int C, int groups, long pixPerStat, int blocksPerStat, float* part) {
     constexpr int VEC = ET<E>::VEC;
-    extern __shared__ float red[];  // [2][rows][C]
+    extern __shared__ float red[];  // [2][rows][C]; row 0 of each plane ends up holding the channel totals
     const int cv = C / VEC;
     const int rows = blockDim.x / cv;
     const int slot = threadIdx.x % cv, r = threadIdx.x / cv;
@@ -77,25 +80,43 @@ __global__ void gn_partial_kernel(GnSrc s, int C, long pixPerStat, int blocksPer
             a += rs[k * C + c];
             b += rq[k * C + c];
         }
-        part[((long)blockIdx.x * 2 + 0) * C + c] = a;
-        part[((long)blockIdx.x * 2 + 1) * C + c] = b;
+        rs[c] = a;      // column c is read and overwritten by this thread only
+        rq[c] = b;
+    }
+    __syncthreads();
+    const int cpg = C / groups;
+    for (int g = threadIdx.x; g < groups; g += blockDim.x) {
+        float a = 0.f, b = 0.f;
+        for (int k = 0; k < cpg; ++k) {
+            a += rs[g * cpg + k];
+            b += rq[g * cpg + k];
+        }
+        part[((long)blockIdx.x * 2 + 0) * groups + g] = a;
+        part[((long)blockIdx.x * 2 + 1) * groups + g] = b;
     }
 }
 
 // one wave per (stat, group)
-__global__ void gn_finalize_kernel(const float* part, int C, int groups, int blocksPerStat,
-                                   long pixPerStat, float eps, float* stats) {
+__global__ void gn_finalize_kernel(const float* part, int groups, int cpg, int blocksPerStat, long pixPerStat,
+                                   float eps, float* stats) {
     const int lane = threadIdx.x & 63;
     const int sg = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int stat = sg / groups, g = sg % groups;
-    const int cpg = C / groups;
+    const float* pp = part + ((long)stat * blocksPerStat * 2) * groups + g;
+    const long st = 2L * groups;
     double a = 0.0, b = 0.0;
-    const int n = blocksPerStat * cpg;
-    for (int i = lane; i < n; i += 64) {
-        const int blk = i / cpg, c = g * cpg + i % cpg;
-        const long o = ((long)(stat * blocksPerStat + blk) * 2) * C + c;
-        a += (double)part[o];
-        b += (double)part[o + C];
+    int i = lane;
+    for (; i + 192 < blocksPerStat; i += 256) {
+        const float a0 = pp[i * st], b0 = pp[i * st + groups];
+        const float a1 = pp[(i + 64) * st], b1 = pp[(i + 64) * st + groups];
+        const float a2 = pp[(i + 128) * st], b2 = pp[(i + 128) * st + groups];
+        const float a3 = pp[(i + 192) * st], b3 = pp[(i + 192) * st + groups];
+        a += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+        b += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+    }
+    for (; i < blocksPerStat; i += 64) {
+        a += (double)pp[i * st];
+        b += (double)pp[i * st + groups];
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -237,15 +258,24 @@ __global__ void gn_apply_kernel(GnApply a) {
 
 }  // namespace
 
+// Workgroups per statistic: ~16 pixels per thread row, so small tensors still spread over many CUs.
+static int gn_blocks_per_stat(const flair_gn_params* p) {
+    const int vec = p->dtype == FLAIR_BF16 ? 8 : 4;
+    const int cv = p->C / vec > 0 ? p->C / vec : 1;
+    const int rows = 256 / cv > 0 ? 256 / cv : 1;
+    const long pix = (long)p->frames_per_stat * p->H * p->W;
+    long bps = (pix + (long)rows * 16 - 1) / ((long)rows * 16);
+    if (bps > 1024) bps = 1024;
+    if (bps < 1) bps = 1;
+    return (int)bps;
+}
+
 extern "C" size_t flair_groupnorm_workspace_bytes(const flair_gn_params* p) {
     if (!p) return 0;
     const int nstat = p->F / p->frames_per_stat;
-    const long pix = (long)p->frames_per_stat * p->H * p->W;
-    int bps = (int)((pix + 255) / 256);
-    if (bps > 1024) bps = 1024;
-    if (bps < 1) bps = 1;
-    // partials [nstat*bps][2][C] + stats [nstat][groups][2]
-    return ((size_t)nstat * bps * 2 * p->C + (size_t)nstat * p->groups * 2) * sizeof(float);
+    const int bps = gn_blocks_per_stat(p);
+    // partials [nstat*bps][2][groups] + stats [nstat][groups][2]
+    return ((size_t)nstat * bps * 2 * p->groups + (size_t)nstat * p->groups * 2) * sizeof(float);
 }
 
 extern "C" int flair_groupnorm_nhwc(const flair_gn_params* p, const void* x0, const void* x1,
@@ -268,12 +298,10 @@ extern "C" int flair_groupnorm_nhwc(const flair_gn_params* p, const void* x0, co
     const int threads = rows * cv;
     const int nstat = p->F / p->frames_per_stat;
     const long pix = (long)p->frames_per_stat * p->H * p->W;
-    int bps = (int)((pix + 255) / 256);
-    if (bps > 1024) bps = 1024;
-    if (bps < 1) bps = 1;
+    const int bps = gn_blocks_per_stat(p);
     FLAIR_CHECK(!film || p->film_ld >= 2 * C, "flair_groupnorm_nhwc: film_ld");
     float* part = reinterpret_cast<float*>(workspace);
-    float* stats = part + (size_t)nstat * bps * 2 * C;
+    float* stats = part + (size_t)nstat * bps * 2 * p->groups;
 
     GnSrc s;
     s.x[0] = x0; s.x[1] = x1;
@@ -281,15 +309,17 @@ extern "C" int flair_groupnorm_nhwc(const flair_gn_params* p, const void* x0, co
     s.ld[0] = p->ld0; s.ld[1] = p->ld1;
     const size_t lds = (size_t)2 * rows * C * sizeof(float);
     if (p->dtype == FLAIR_BF16)
-        hipLaunchKernelGGL(gn_partial_kernel<bf16_t>, dim3(nstat * bps), dim3(threads), lds, stream, s, C, pix, bps, part);
+        hipLaunchKernelGGL(gn_partial_kernel<bf16_t>, dim3(nstat * bps), dim3(threads), lds, stream, s, C, p->groups, pix, bps,
+                           part);
     else
-        hipLaunchKernelGGL(gn_partial_kernel<float>, dim3(nstat * bps), dim3(threads), lds, stream, s, C, pix, bps, part);
+        hipLaunchKernelGGL(gn_partial_kernel<float>, dim3(nstat * bps), dim3(threads), lds, stream, s, C, p->groups, pix, bps,
+                           part);
     FLAIR_LAUNCH_CHECK();
     const int sg = nstat * p->groups;
     FLAIR_CHECK(sg % 4 == 0 || sg < 4, "flair_groupnorm_nhwc: groups");
     const int wavesPerBlock = sg >= 4 ? 4 : sg;
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(sg / wavesPerBlock), dim3(64 * wavesPerBlock), 0, stream,
-                       part, C, p->groups, bps, pix, p->eps, stats);
+                       part, p->groups, C / p->groups, bps, pix, p->eps, stats);
     FLAIR_LAUNCH_CHECK();
 
     GnApply a;
