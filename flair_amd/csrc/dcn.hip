@@ -74,7 +74,7 @@ __device__ __forceinline__ int tile_off(int row, int chunk) {
 __device__ __forceinline__ float fast_tanh(float x) {
     // 1 - 2/(e^{2x}+1); |err| ~ 1e-7 relative, saturates cleanly for large |x|
     const float e = __expf(2.f * x);
-    return 1.f - 2.f / (e + 1.f);
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);   // v_rcp_f32 (1 ulp) instead of an IEEE divide
 }
 
 // Workgroup = TP = 32*NPF consecutive pixels of one frame x ALL output channels (NCF
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(32 * NPF * TPP, (NCF >= 4 ? 32 * NPF * TPP / 256 : 
         const float2 fl = g < G / 2 ? fl1 : fl2;
         const float sy = (float)(ph - 1 + ikh) + a.maxMag * fast_tanh(ry) + fl.y;
         const float sx = (float)(pw - 1 + ikw) + a.maxMag * fast_tanh(rx) + fl.x;
-        const float mk = 1.f / (1.f + __expf(-rm));
+        const float mk = __builtin_amdgcn_rcpf(1.f + __expf(-rm));
         const float fy = floorf(sy), fx = floorf(sx);
         const float ay = sy - fy, ax = sx - fx;
         // clamp before the int conversion so wild offsets cannot overflow
@@ -186,12 +186,15 @@ __global__ __launch_bounds__(32 * NPF * TPP, (NCF >= 4 ? 32 * NPF * TPP / 256 : 
         const unsigned ld = (unsigned)(second ? a.xLd[1] : a.xLd[0]) * ESZ;
         const unsigned coff = (unsigned)(c - (second ? halfC : 0)) * ESZ;
         const __amdgpu_buffer_rsrc_t xr = second ? xr1 : xr0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int yy = y0 + (i >> 1), xx = x0 + (i & 1);
-            const bool ok = pvalid && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
-            r.c[i] = buf_load16(xr, ok ? (frameBase + (unsigned)(yy * a.W + xx)) * ld + coff : FLAIR_OOB);
-        }
+        // one multiply for the top-left corner, the other three are adds (v_mul_lo_u32 is quarter rate)
+        const unsigned o00 = (frameBase + (unsigned)(y0 * a.W + x0)) * ld + coff;
+        const unsigned rowStep = (unsigned)a.W * ld;
+        const bool yok0 = pvalid && (unsigned)y0 < (unsigned)a.H, yok1 = pvalid && (unsigned)(y0 + 1) < (unsigned)a.H;
+        const bool xok0 = (unsigned)x0 < (unsigned)a.W, xok1 = (unsigned)(x0 + 1) < (unsigned)a.W;
+        r.c[0] = buf_load16(xr, yok0 && xok0 ? o00 : FLAIR_OOB);
+        r.c[1] = buf_load16(xr, yok0 && xok1 ? o00 + ld : FLAIR_OOB);
+        r.c[2] = buf_load16(xr, yok1 && xok0 ? o00 + rowStep : FLAIR_OOB);
+        r.c[3] = buf_load16(xr, yok1 && xok1 ? o00 + rowStep + ld : FLAIR_OOB);
 #pragma unroll
         for (int j = 0; j < WR; ++j) {
             const int id = tid + j * NT;

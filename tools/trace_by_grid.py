@@ -10,7 +10,8 @@ for r in rows:
     n = r["Kernel_Name"]
     if pat not in n:
         continue
-    short = n.split("(")[0].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")[:60]
+    short = n.replace("void ", "").replace("(anonymous namespace)::", "").replace("unsigned short", "bf16")
+    short = short.split("(")[0][:60]
     key = (short, int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1), int(r["Workgroup_Size_X"]))
     d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     agg[key][0] += 1
