@@ -1,0 +1,53 @@
+"""HBM traffic per kernel launch from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE).
+
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE -d <fetch_dir> -o b --output-format csv -- python bench.py ...
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE -d <write_dir> -o b --output-format csv -- python bench.py ...
+    python tools/pmc_traffic.py <fetch_dir> <write_dir>
+
+FETCH_SIZE is doubled (gfx950 tallies 128-byte read requests at 64 bytes, MI355X_MICROARCH.md).
+"""
+import collections
+import csv
+import re
+import sys
+
+
+def key(n):
+    m = re.search(r"namespace\)::(\w+(?:<[^>]*>)?)", n)
+    return (m.group(1) if m else n[:50]).replace("unsigned short", "bf16")
+
+
+def load(d, cname):
+    agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
+    for r in csv.DictReader(open(f"{d}/b_counter_collection.csv")):
+        if r["Counter_Name"] != cname:
+            continue
+        k = key(r["Kernel_Name"])
+        agg[k][0] += 1
+        agg[k][1] += float(r["Counter_Value"])
+        agg[k][2] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    return agg
+
+
+def main():
+    f, w = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+    print("# rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- "
+          "python bench.py --steps 2 --warmup 1 --no-cpu-baseline")
+    print("# HBM bytes per launch = FETCH_SIZE*1024*2 (gfx950 reports half of a wide coalesced read, "
+          "MI355X_MICROARCH.md) + WRITE_SIZE*1024")
+    rows = []
+    for k in f:
+        calls = f[k][0]
+        fetch = f[k][1] * 1024 * 2 / calls
+        wk = w.get(k, [1, 0, 0])
+        write = wk[1] * 1024 / max(wk[0], 1)
+        dur = f[k][2] / calls / 1e3
+        rows.append(((fetch + write) * calls, k, calls, fetch, write, dur))
+    rows.sort(reverse=True)
+    print(f"{'kernel':58s} {'calls':>6s} {'read MB':>9s} {'write MB':>9s} {'avg us':>8s} {'GB/s':>7s}")
+    for _, k, calls, fe, wr, dur in rows[:16]:
+        print(f"{k:58s} {calls:6d} {fe/1e6:9.2f} {wr/1e6:9.2f} {dur:8.1f} {(fe+wr)/dur/1e3:7.0f}")
+
+
+if __name__ == "__main__":
+    main()
