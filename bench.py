@@ -34,7 +34,8 @@ TOTAL_STEPS = 250
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense, MI355X_MICROARCH.md
 CONV_VARIANTS = {0: "conv_igemm_kernel<128co x 128px>", 1: "conv_igemm_kernel<64co x 128px>",
                  2: "conv_igemm_kernel<64co x 64px>", 3: "conv3x3_halo_kernel<8 rows>",
-                 4: "conv3x3_halo_kernel<4 rows>", 5: "conv3x3_halo_kernel<2 rows>"}
+                 4: "conv3x3_halo_kernel<4 rows>", 5: "conv3x3_halo_kernel<2 rows>",
+                 6: "conv3x3_halo_ks_kernel<8 rows>", 7: "conv3x3_halo_ks_kernel<4 rows>"}
 
 
 def parse():

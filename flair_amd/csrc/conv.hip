@@ -69,6 +69,12 @@ template <> struct Mma<bf16_t> {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[1]),
                                                       __builtin_bit_cast(bf16x8, b[1]), acc, 0, 0, 0);
     }
+    // one half of the K-step (16 channels)
+    static __device__ __forceinline__ void run1(const uint4& a, const uint4& b, f32x16& acc) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
+                                                      acc, 0, 0, 0);
+    }
+    static constexpr int MFMA_PER_HALF = 1;
 };
 
 // f32: one K-step = 16 channels = eight 32x32x2 MFMAs.  Lane half h consumes channels
@@ -83,6 +89,14 @@ template <> struct Mma<float> {
         for (int s = 0; s < 8; ++s)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[s], acc, 0, 0, 0);
     }
+    static __device__ __forceinline__ void run1(const uint4& a, const uint4& b, f32x16& acc) {
+        const float* af = reinterpret_cast<const float*>(&a);
+        const float* bf = reinterpret_cast<const float*>(&b);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[s], acc, 0, 0, 0);
+    }
+    static constexpr int MFMA_PER_HALF = 4;
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {
@@ -421,6 +435,265 @@ int launch_halo(const ConvArgs& a0, hipStream_t s) {
     return FLAIR_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// K-split halo kernel for launches of at most one workgroup per CU (the per-frame convolutions of
+// the BasicVSR++ recurrence): same TH x 32 px x 64 cout tile and staging as above, but a wavefront
+// owns RPW image rows x 64 couts x ONE 16-channel half of the K step (wave = row group + k-half *
+// TH/RPW), so the tile is spread over twice the wavefronts per row group: the serial MFMA chain of
+// a chunk halves (and with RPW = 2 the weight fragments are reused across two rows: 1.0
+// ds_read_b128 per MFMA instead of 1.5 -- the loop above is bound by LDS bandwidth, not by the
+// matrix cores).  The two k-halves of a tile are summed through the LDS staging tile of the
+// epilogue.  Two LDS stages (one barrier per chunk), one workgroup per CU (up to 146 KB of LDS,
+// 256 VGPRs).  Needs Cout % 8 == 0.
+template <typename E, int TH, int RPW, int CF>
+__global__ __launch_bounds__(256 * TH / RPW / CF, (256 * TH / RPW / CF) / 256) void conv3x3_halo_ks_kernel(ConvArgs a) {
+    constexpr int NRG = TH / RPW;                  // row groups
+    constexpr int NCG = 2 / CF;                    // cout-fragment groups (CF fragments of 32 couts per wave)
+    constexpr int NW = 2 * NRG * NCG, NT = 64 * NW;
+    constexpr int BKE = Mma<E>::BKE;
+    constexpr int VEC = ET<E>::VEC;
+    constexpr unsigned ESZ = sizeof(E);
+    constexpr int HW_ = 34, PITCH = 80;
+    constexpr int HALO_PIECES = (TH + 2) * HW_ * 4;
+    constexpr int W_PIECES = 64 * 9 * 4;
+    constexpr int HI = (HALO_PIECES + NT - 1) / NT;
+    constexpr int WI = (W_PIECES + NT - 1) / NT;
+    constexpr int HALO_BYTES = (TH + 2) * HW_ * PITCH;
+    constexpr int STAGE_BYTES = HALO_BYTES + 64 * 9 * PITCH;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int rp = wave % NRG, kh2 = (wave / NRG) & 1, cg = wave / (2 * NRG);   // row group, k-half, cout group
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int coTile = bid % a.nCoTiles;
+    int rest = bid / a.nCoTiles;
+    const int tilesW = a.W / 32, tilesH = (a.H + TH - 1) / TH;
+    const int tw = rest % tilesW;
+    rest /= tilesW;
+    const int th = rest % tilesH;
+    const int t = rest / tilesH;
+    const int h0 = th * TH, w0 = tw * 32, co0 = coTile * 64;
+    const int taps = a.KT * 9;
+    const int pt = a.KT / 2;
+
+    uint4 hreg[HI], wreg[WI];
+    int dt = -pt, seg = 0, cb = 0, segOff = 0;
+    auto dt_valid = [&](int d) { return (unsigned)(t + d) < (unsigned)a.T; };
+    while (dt <= pt && !dt_valid(dt)) ++dt;
+
+    int hpix[HI];
+    unsigned hq[HI], woff[WI];
+#pragma unroll
+    for (int i = 0; i < HI; ++i) {
+        const int id = i * NT + tid;
+        const int pix = id >> 2;
+        const int r = pix / HW_, c = pix % HW_;
+        const int hh = h0 + r - 1, ww = w0 + c - 1;
+        const bool ok = id < HALO_PIECES && (unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W;
+        hpix[i] = ok ? hh * a.W + ww : -1;
+        hq[i] = (id & 3) * VEC * ESZ;
+    }
+    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.w, a.wBytes);
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+        const int id = i * NT + tid;
+        const int row = id >> 2;
+        const int co = row / 9, tap9 = row % 9;
+        const bool ok = id < W_PIECES && co0 + co < a.Cout;
+        woff[i] = ok ? (unsigned)(((co0 + co) * taps + tap9) * a.CinTot + (id & 3) * VEC) * ESZ : FLAIR_OOB;
+    }
+    auto issue = [&]() {
+        const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.x[seg], a.segBytes[seg]);
+        const unsigned ld = (unsigned)a.segLd[seg] * ESZ;
+        const int fbase = (t + dt) * a.H * a.W;
+        const unsigned cofs = (unsigned)(cb * BKE) * ESZ;
+#pragma unroll
+        for (int i = 0; i < HI; ++i)
+            hreg[i] = buf_load16(xr, hpix[i] >= 0 ? (unsigned)(fbase + hpix[i]) * ld + cofs + hq[i] : FLAIR_OOB);
+        const unsigned kofs = (unsigned)((dt + pt) * 9 * a.CinTot + segOff + cb * BKE) * ESZ;
+#pragma unroll
+        for (int i = 0; i < WI; ++i) wreg[i] = buf_load16(wrs, woff[i] == FLAIR_OOB ? FLAIR_OOB : woff[i] + kofs);
+        // advance the K walk (exhausted when dt > pt)
+        ++cb;
+        if (cb * BKE >= a.segC[seg]) {
+            cb = 0;
+            segOff += a.segC[seg];
+            if (++seg >= a.nseg) {
+                seg = 0;
+                segOff = 0;
+                ++dt;
+                while (dt <= pt && !dt_valid(dt)) ++dt;
+            }
+        }
+    };
+    auto write_lds = [&](int stage) {
+        char* sh = smem + stage * STAGE_BYTES;
+        char* sw = sh + HALO_BYTES;
+#pragma unroll
+        for (int i = 0; i < HI; ++i) {
+            const int id = i * NT + tid;
+            if (id < HALO_PIECES) *reinterpret_cast<uint4*>(sh + (id >> 2) * PITCH + (id & 3) * 16) = hreg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            const int id = i * NT + tid;
+            if (id < W_PIECES) *reinterpret_cast<uint4*>(sw + (id >> 2) * PITCH + (id & 3) * 16) = wreg[i];
+        }
+    };
+    int nValidDt = 0;
+    for (int d = -pt; d <= pt; ++d) nValidDt += dt_valid(d) ? 1 : 0;
+    const int nch = nValidDt * (a.CinTot / BKE);
+
+    f32x16 acc[RPW][CF];   // [row of the group][cout fragment]
+#pragma unroll
+    for (int j = 0; j < RPW; ++j)
+#pragma unroll
+        for (int i = 0; i < CF; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+
+    const int ck = 16 * Mma<E>::chunk(kh2, lh);      // this wave's 16-byte piece of every staged row
+    auto compute = [&](int stage) {
+        const char* sh = smem + stage * STAGE_BYTES;
+        const char* hb = sh + ((RPW * rp * HW_) + lr) * PITCH + ck;
+        const char* wb0 = sh + HALO_BYTES + ((cg * CF * 32 + lr) * 9) * PITCH + ck;
+        uint4 fa[2][CF], fb[2][RPW];
+        auto load_tap = [&](int set, int tap9) {
+            const int kh = tap9 / 3, kw = tap9 % 3;
+#pragma unroll
+            for (int i = 0; i < CF; ++i)
+                fa[set][i] = *reinterpret_cast<const uint4*>(wb0 + (i * 32 * 9 + tap9) * PITCH);
+#pragma unroll
+            for (int j = 0; j < RPW; ++j)
+                fb[set][j] = *reinterpret_cast<const uint4*>(hb + ((kh + j) * HW_ + kw) * PITCH);
+        };
+        load_tap(0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, CF + RPW, 0);
+#pragma unroll
+        for (int tap9 = 0; tap9 < 9; ++tap9) {
+            const int set = tap9 & 1;
+            if (tap9 < 8) load_tap(set ^ 1, tap9 + 1);
+#pragma unroll
+            for (int j = 0; j < RPW; ++j)
+#pragma unroll
+                for (int i = 0; i < CF; ++i) Mma<E>::run1(fa[set][i], fb[set][j], acc[j][i]);
+            // pin the interleave: next tap's LDS reads are issued ahead of this tap's MFMAs
+            if (tap9 < 8) __builtin_amdgcn_sched_group_barrier(0x100, CF + RPW, 0);
+            __builtin_amdgcn_sched_group_barrier(0x8, CF * RPW * Mma<E>::MFMA_PER_HALF, 0);
+        }
+    };
+
+    // two-stage pipeline: chunk k is multiplied out of stage k&1 while chunk k+1 is written to the
+    // other stage and chunk k+2 is in flight from L2 (one register set, one barrier per chunk)
+    issue();
+    write_lds(0);
+    if (nch > 1) issue();
+    __syncthreads();
+    for (int k = 0; k < nch; ++k) {
+        compute(k & 1);
+        if (k + 1 < nch) {
+            write_lds((k + 1) & 1);      // stage (k+1)&1 was last read before the previous barrier
+            if (k + 2 < nch) issue();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: sum the two k-halves in the f32 staging tile, then transposed, coalesced stores
+    constexpr int FPITCH = 64 * 4 + 16;
+    constexpr int CHUNKS = 64 / VEC;                         // 16-byte output pieces per pixel
+    __syncthreads();                                         // LDS is free: all fragment reads are done
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        if (kh2 == pass) {
+#pragma unroll
+            for (int j = 0; j < RPW; ++j) {
+                char* tile = smem + (RPW * rp + j) * 32 * FPITCH + lr * FPITCH;
+#pragma unroll
+                for (int i = 0; i < CF; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float4* dst = reinterpret_cast<float4*>(tile + ((cg * CF + i) * 32 + 8 * g + 4 * lh) * 4);
+                        float4 v = make_float4(acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2],
+                                               acc[j][i][4 * g + 3]);
+                        if (pass == 1) {
+                            const float4 o = *dst;
+                            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                        }
+                        *dst = v;
+                    }
+            }
+        }
+        __syncthreads();
+    }
+    constexpr int PARTS = NW / TH;                           // wavefronts sharing one output row
+    const int orow = wave % TH, part = wave / TH;
+    const int h = h0 + orow;
+    if (h >= a.H) return;
+    const char* tile = smem + orow * 32 * FPITCH;
+    const long prow = ((long)t * a.H + h) * a.W + w0;
+#pragma unroll
+    for (int it0 = 0; it0 < 32 * CHUNKS / 64; it0 += PARTS) {
+        const int it = it0 + part;
+        const int id = it * 64 + lane;
+        const int px = id / CHUNKS, ch = id % CHUNKS;
+        const int co = co0 + ch * VEC;
+        if (co >= a.Cout) continue;
+        const long p = prow + px;
+        float v[VEC];
+        const float* src = reinterpret_cast<const float*>(tile + px * FPITCH) + ch * VEC;
+#pragma unroll
+        for (int e = 0; e < VEC; e += 4) {
+            const float4 q = *reinterpret_cast<const float4*>(src + e);
+            v[e] = q.x; v[e + 1] = q.y; v[e + 2] = q.z; v[e + 3] = q.w;
+        }
+        if (a.bias) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[e] += a.bias[co + e];
+        }
+        if (a.fbias) {
+            const float* fb = a.fbias + (long)t * a.fbiasLd + co;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[e] += fb[e];
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[e] = apply_act(v[e], a.act);
+        if (a.res0) {
+            float r[VEC];
+            Vec16<E>::load(reinterpret_cast<const E*>(a.res0) + p * a.res0Ld + co, r);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[e] += r[e];
+        }
+        if (a.res1) {
+            float r[VEC];
+            Vec16<E>::load(reinterpret_cast<const E*>(a.res1) + p * a.res1Ld + co, r);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[e] += r[e];
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[e] *= a.outScale;
+        Vec16<E>::store(reinterpret_cast<E*>(a.y) + p * a.yLd + co, v);
+    }
+}
+
+template <typename E, int TH, int RPW, int CF>
+int launch_halo_ks(const ConvArgs& a0, hipStream_t s) {
+    ConvArgs a = a0;
+    a.nCoTiles = cdiv(a.Cout, 64);
+    const int grid = a.T * cdiv(a.H, TH) * (a.W / 32) * a.nCoTiles;
+    const size_t lds = 2 * ((size_t)(TH + 2) * 34 * 80 + 64 * 9 * 80);
+    static bool attr = false;
+    if (!attr) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_ks_kernel<E, TH, RPW, CF>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        FLAIR_CHECK(e == hipSuccess, "flair_conv_nhwc: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr = true;
+    }
+    hipLaunchKernelGGL((conv3x3_halo_ks_kernel<E, TH, RPW, CF>), dim3(grid), dim3(256 * TH / RPW / CF), lds, s, a);
+    FLAIR_LAUNCH_CHECK();
+    return FLAIR_OK;
+}
+
 // TC x TP block tile (couts x pixels), 4 waves arranged WC x WP.
 template <typename E, int TC, int TP, int WC, int WP>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
@@ -659,13 +932,16 @@ int choose_split(const ConvArgs& a, int variant) {
 }
 
 // Kernel choice.  3..5: halo kernel with 8/4/2 image rows per workgroup (3x3 spatial taps,
-// W a multiple of 32); 0..2: im2col tiles 128 couts x 128 pixels, 64 x 128, 64 x 64.
+// W a multiple of 32); 6/7: its K-split form (8/4 rows) when the launch is exactly one round of
+// 256 workgroups; 0..2: im2col tiles 128 couts x 128 pixels, 64 x 128, 64 x 64.
 // Either way keep >= ~2 workgroups per CU when the problem allows it.
 int choose_variant(const ConvArgs& a) {
     if (a.stride == 1 && a.KH == 3 && a.KW == 3 && a.W % 32 == 0 && a.H >= 2) {
         const long per = (long)a.T * (a.W / 32) * cdiv(a.Cout, 64);
-        if (per * cdiv(a.H, 8) >= 256) return 3;
-        if (per * cdiv(a.H, 4) >= 256) return 4;
+        // single-round launches (<= one workgroup per CU): K-split kernel, twice the wavefronts
+        const bool ks = a.Cout % 8 == 0;
+        if (per * cdiv(a.H, 8) >= 256) return ks && per * cdiv(a.H, 8) <= 256 ? 6 : 3;
+        if (per * cdiv(a.H, 4) >= 256) return ks && per * cdiv(a.H, 4) <= 256 ? 7 : 4;
         return 5;
     }
     const long tiles128 = (long)cdiv(a.P, 128) * cdiv(a.Cout, 128);
@@ -686,6 +962,8 @@ int dispatch(const ConvArgs& a0, hipStream_t s) {
         case 2: return launch<E, 64, 64, 2, 2>(a, s);
         case 3: return launch_halo<E, 8, 1, 1>(a, s);
         case 4: return launch_halo<E, 4, 1, 1>(a, s);
+        case 6: return launch_halo_ks<E, 8, 1, 2>(a, s);
+        case 7: return launch_halo_ks<E, 4, 1, 2>(a, s);
         default: return launch_halo<E, 2, 1, 1>(a, s);
     }
 }

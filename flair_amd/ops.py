@@ -144,6 +144,22 @@ def conv(xs, weight, bias, cout, kernel, *, out=None, act=ACT_NONE, res0=None, r
 CONV_PROFILE = None
 
 
+def conv_variant(T, H, W, cins, cout, kernel, dtype=torch.bfloat16, stride=1):
+    """Kernel variant flair_conv_nhwc dispatches this geometry to (flair_conv_variant); host-only."""
+    p = ConvParams()
+    p.dtype = 1 if dtype == torch.bfloat16 else 0      # FLAIR_BF16 / FLAIR_F32
+    p.T, p.H, p.W = T, H, W
+    p.KT, p.KH, p.KW = kernel
+    p.Cout = cout
+    p.nseg = len(cins)
+    for i, c in enumerate(cins):
+        p.seg_c[i] = c
+        p.seg_ld[i] = c
+    p.stride = stride
+    p.y_ld = cout
+    return lib().flair_conv_variant(ctypes.byref(p))
+
+
 def _conv_ws_bytes(p):
     f = lib().flair_conv_workspace_bytes
     f.restype = ctypes.c_size_t

@@ -95,7 +95,8 @@ int flair_conv_nhwc(const flair_conv_params* p, const void* const* x, const void
                     void* y, void* workspace, size_t workspace_bytes, hipStream_t stream);
 /* Which kernel variant flair_conv_nhwc launches for these parameters (profiling aid):
  * im2col tiles 0 = 128 couts x 128 pixels, 1 = 64 x 128, 2 = 64 x 64 per workgroup;
- * halo kernel (3x3 spatial taps, W % 32 == 0) 3 / 4 / 5 = 8 / 4 / 2 image rows per workgroup. */
+ * halo kernel (3x3 spatial taps, W % 32 == 0) 3 / 4 / 5 = 8 / 4 / 2 image rows per workgroup;
+ * 6 / 7 = K-split halo kernel with 8 / 4 rows (launches of exactly 256 workgroups: one frame). */
 int flair_conv_variant(const flair_conv_params* p);
 
 

@@ -38,6 +38,11 @@ def _ops():
     (1, 30, 32, [64, 64, 64, 32], 64, (1, 3, 3), 2, 2),
     (5, 16, 32, [64], 128, (3, 3, 3), 0, 1),
     (16, 36, 64, [32], 64, (3, 3, 3), 3, 0),
+    (16, 72, 64, [32], 64, (3, 3, 3), 1, 1),
+    (2, 136, 128, [64], 64, (1, 3, 3), 2, 1),
+    # K-split halo kernel: launches of exactly 256 workgroups (one 256^2 / 128^2 frame)
+    (1, 256, 256, [64, 32], 64, (1, 3, 3), 2, 2),
+    (4, 64, 64, [64], 128, (3, 3, 3), 0, 1),
 ])
 def test_conv(dev, dtype, case):
     ops = _ops()
@@ -67,6 +72,18 @@ def test_conv(dev, dtype, case):
     y = ops.conv(xs, wp, b.to(dev), cout, k, act=act, res0=rs[0], res1=rs[1], out_scale=0.5)
     torch.cuda.synchronize()
     assert_close(from_clip(y), ref, dtype, f"conv {case}")
+
+
+def test_conv_cases_cover_every_kernel_variant():
+    """The geometries above dispatch to all 8 conv kernel variants (flair_conv_variant)."""
+    ops = _ops()
+    geo = [(2, 16, 16, [64], 64, (1, 3, 3)), (16, 64, 64, [64], 64, (1, 3, 3)), (2, 128, 128, [64, 64], 64, (1, 3, 3)),
+           (1, 64, 32, [128], 432, (1, 3, 3)), (1, 30, 32, [64, 64, 64, 32], 64, (1, 3, 3)),
+           (16, 72, 64, [32], 64, (3, 3, 3)), (2, 136, 128, [64], 64, (1, 3, 3)),
+           (1, 256, 256, [64, 32], 64, (1, 3, 3)), (4, 64, 64, [64], 128, (3, 3, 3)),
+           (16, 256, 256, [64], 64, (1, 1, 1)), (16, 128, 128, [128], 128, (1, 1, 1)), (16, 4, 4, [512], 512, (3, 3, 3))]
+    seen = {ops.conv_variant(T, H, W, segs, cout, k) for T, H, W, segs, cout, k in geo}
+    assert seen == set(range(8)), seen
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
