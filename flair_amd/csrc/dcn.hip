@@ -10,10 +10,11 @@
 //
 //   raw  : [F][H][W][rawLd]  conv_offset output, 27*G channels in TAP-MAJOR order (the host
 //          permutes the output channels of the last conv_offset convolution when it packs
-//          its weights, which is free):
-//            raw[2*(k*G+g)+{0,1}] = (dy,dx) pre-activation of group g, tap k
-//            raw[18*G + k*G + g]  = mask pre-activation
-//          (reference order: 2*(g*9+k)+{0,1} and 18*G + g*9 + k)
+//          its weights, which is free): tap k owns the 3*G contiguous channels [3*G*k, 3*G*(k+1)),
+//            raw[3*G*k + 2*g + {0,1}] = (dy,dx) pre-activation of group g, tap k
+//            raw[3*G*k + 2*G + g]     = mask pre-activation
+//          (reference order: 2*(g*9+k)+{0,1} and 18*G + g*9 + k), so one tap of one pixel is a
+//          single 96-byte run (bf16) and consecutive taps share cache lines
 //   dy,dx(g,k) = M*tanh(raw..) + flow_g.{y,x};  flow_g = flow1 (g < G/2) else flow2
 //   m(g,k)     = sigmoid(raw..)
 //   Y[p][co]   = bias[co] + sum_{k,ci} Wt[co][k][ci] * m(g(ci),k) * bilinear(X[ci], p + pk + d(g(ci),k))
@@ -103,14 +104,16 @@ __global__ __launch_bounds__(32 * NPF * TPP, (NCF >= 4 ? 32 * NPF * TPP / 256 : 
     constexpr int BUF = (TC + TP) * CPR * 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int G = a.G;
-    const int slabPieces = 3 * G * (int)ESZ / 16, offPieces = 2 * G * (int)ESZ / 16;
+    const int slabPieces = 3 * G * (int)ESZ / 16;
     const int rawPitch = 3 * G * (int)ESZ + 16;               // +16 B: spreads pixels over banks
     char* sraw = smem;
     char* stile = smem + 2 * TP * rawPitch;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 31, lh = lane >> 5;
-    const long p0 = (long)blockIdx.x * TP;
+    // each XCD (own L2) works on one contiguous eighth of the frame: the gathered features of
+    // its tiles stay in that L2 instead of every L2 fetching the whole frame
+    const long p0 = (long)xcd_remap(blockIdx.x, gridDim.x) * TP;
     const int q = tid % TPP, srow = tid / TPP;
     long p = p0 + srow;
     const bool pvalid = p < a.P;
@@ -134,9 +137,7 @@ __global__ __launch_bounds__(32 * NPF * TPP, (NCF >= 4 ? 32 * NPF * TPP / 256 : 
             const int id = tid + j * NT;
             const int px = id / slabPieces, pc = id - px * slabPieces;
             const long pp = p0 + px;
-            const bool isOff = pc < offPieces;
-            const unsigned within = isOff ? (unsigned)(2 * tap * G) * ESZ + pc * 16
-                                          : (unsigned)(18 * G + tap * G) * ESZ + (pc - offPieces) * 16;
+            const unsigned within = (unsigned)(3 * tap * G) * ESZ + pc * 16;
             reg[j] = buf_load16(rr, px < TP && pp < a.P ? (unsigned)(pp * a.rawLd * ESZ) + within : FLAIR_OOB);
             dst[j] = px < TP ? ((tap & 1) * TP + px) * rawPitch + pc * 16 : -1;
         }

@@ -365,15 +365,16 @@ def resize(x, size, mode, *, channels=None, out=None, scale_c0=1.0, scale_c1=1.0
 def dcn_raw_permutation(groups):
     """Index tensor taking the reference's conv_offset channel order (o1 | o2 | mask with
     group-major (g*9+k) indexing, unet_new.py:877-885) to the tap-major order flair_dcn_align
-    reads: new[2*(k*G+g)+e] = old[2*(g*9+k)+e], new[18G + k*G + g] = old[18G + g*9 + k].
+    reads (tap k owns channels [3Gk, 3G(k+1))): new[3Gk + 2g + e] = old[2*(g*9+k)+e],
+    new[3Gk + 2G + g] = old[18G + g*9 + k].
     Applied to the OUTPUT channels of the last conv_offset convolution when it is packed."""
     G = groups
     perm = torch.empty(27 * G, dtype=torch.long)
     for k in range(9):
         for g in range(G):
             for e in range(2):
-                perm[2 * (k * G + g) + e] = 2 * (g * 9 + k) + e
-            perm[18 * G + k * G + g] = 18 * G + g * 9 + k
+                perm[3 * G * k + 2 * g + e] = 2 * (g * 9 + k) + e
+            perm[3 * G * k + 2 * G + g] = 18 * G + g * 9 + k
     return perm
 
 

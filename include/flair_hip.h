@@ -256,9 +256,10 @@ int flair_resize_nhwc(const void* x, int dtype, int x_ld, int F, int Hi, int Wi,
  * Fused offset/mask activation + modulated deformable 3x3 conv (unet_new.py:877-898;
  * same operator as dcn/src/deform_conv_cuda_kernel.cu:571-633 + deform_conv_cuda.cpp:540-560).
  *   x0|x1 : the two halves of the 2c input channels (feat_prop | feat_n2)
- *   raw   : conv_offset output, 27*G channels, pixel stride raw_ld, in TAP-MAJOR order:
- *             raw[2*(k*G+g)+{0,1}] = (dy,dx) pre-activation of group g / tap k,
- *             raw[18*G + k*G + g]  = mask pre-activation
+ *   raw   : conv_offset output, 27*G channels, pixel stride raw_ld, in TAP-MAJOR order
+ *           (tap k owns the 3*G contiguous channels [3*G*k, 3*G*(k+1))):
+ *             raw[3*G*k + 2*g + {0,1}] = (dy,dx) pre-activation of group g / tap k,
+ *             raw[3*G*k + 2*G + g]     = mask pre-activation
  *           (the reference's o1|o2|mask order is 2*(g*9+k)+{0,1} and 18*G + g*9 + k; the
  *           caller permutes the output channels of the last conv_offset convolution once,
  *           when it packs that layer's weights).  G in {8, 16}; Cin/G a power of two.
