@@ -216,13 +216,14 @@ void conv3x3_halo_kernel(ConvArgs a) {
     }
 
     auto issue = [&](uint4 (&hr)[HI], uint4 (&wr)[WI]) {
-        const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.x[seg], a.segBytes[seg]);
+        // buffer resource = ONE input frame (clips may exceed the 2 GiB a resource can address)
         const unsigned ld = (unsigned)a.segLd[seg] * ESZ;
-        const int fbase = (t + dt) * a.H * a.W;
+        const char* frame = reinterpret_cast<const char*>(a.x[seg]) + (size_t)(t + dt) * a.H * a.W * ld;
+        const __amdgpu_buffer_rsrc_t xr = make_rsrc(frame, a.segBytes[seg]);
         const unsigned cofs = (unsigned)(cb * BKE) * ESZ;
 #pragma unroll
         for (int i = 0; i < HI; ++i) {
-            const unsigned off = hpix[i] >= 0 ? (unsigned)(fbase + hpix[i]) * ld + cofs + hq[i] : FLAIR_OOB;
+            const unsigned off = hpix[i] >= 0 ? (unsigned)hpix[i] * ld + cofs + hq[i] : FLAIR_OOB;
             hr[i] = buf_load16(xr, off);
         }
         const unsigned kofs = (unsigned)((dt + pt) * 9 * a.CinTot + segOff + cb * BKE) * ESZ;
@@ -504,13 +505,13 @@ __global__ __launch_bounds__(256 * TH / RPW / CF, (256 * TH / RPW / CF) / 256) v
         woff[i] = ok ? (unsigned)(((co0 + co) * taps + tap9) * a.CinTot + (id & 3) * VEC) * ESZ : FLAIR_OOB;
     }
     auto issue = [&]() {
-        const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.x[seg], a.segBytes[seg]);
         const unsigned ld = (unsigned)a.segLd[seg] * ESZ;
-        const int fbase = (t + dt) * a.H * a.W;
+        const char* frame = reinterpret_cast<const char*>(a.x[seg]) + (size_t)(t + dt) * a.H * a.W * ld;
+        const __amdgpu_buffer_rsrc_t xr = make_rsrc(frame, a.segBytes[seg]);   // one input frame
         const unsigned cofs = (unsigned)(cb * BKE) * ESZ;
 #pragma unroll
         for (int i = 0; i < HI; ++i)
-            hreg[i] = buf_load16(xr, hpix[i] >= 0 ? (unsigned)(fbase + hpix[i]) * ld + cofs + hq[i] : FLAIR_OOB);
+            hreg[i] = buf_load16(xr, hpix[i] >= 0 ? (unsigned)hpix[i] * ld + cofs + hq[i] : FLAIR_OOB);
         const unsigned kofs = (unsigned)((dt + pt) * 9 * a.CinTot + segOff + cb * BKE) * ESZ;
 #pragma unroll
         for (int i = 0; i < WI; ++i) wreg[i] = buf_load16(wrs, woff[i] == FLAIR_OOB ? FLAIR_OOB : woff[i] + kofs);
@@ -737,6 +738,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     }
     const int taps = a.KT * a.KH * a.KW;
     const int pt = a.KT / 2, ph = a.KH / 2, pw = a.KW / 2;
+    const int tFirst = (int)(p0 / ((long)a.H * a.W));                       // frame of the tile's first pixel
+    const int tileFrames = (int)((TP + (long)a.H * a.W - 1) / ((long)a.H * a.W)) + 1;   // frames one tile can span
 
     uint4 xreg[XR], wreg[WR];
 
@@ -755,15 +758,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.w, a.wBytes);
     constexpr unsigned ESZ = sizeof(E);
     auto issue_loads = [&]() {
-        const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.x[seg], a.segBytes[seg]);
+        // buffer resource = the frames this pixel tile can touch for the current temporal tap,
+        // starting at frame fb (a whole clip may exceed the 2 GiB one resource can address)
         const int ld = a.segLd[seg];
+        int fb = tFirst + dt;
+        fb = fb < 0 ? 0 : (fb >= a.T ? a.T - 1 : fb);
+        int nfr = a.T - fb;
+        if (nfr > tileFrames) nfr = tileFrames;
+        const size_t frameBytes = (size_t)a.Hin * a.Win * ld * ESZ;
+        const __amdgpu_buffer_rsrc_t xr =
+            make_rsrc(reinterpret_cast<const char*>(a.x[seg]) + fb * frameBytes, (unsigned)(nfr * frameBytes));
         const int coff = cb * BKE + chunk * VEC;
 #pragma unroll
         for (int i = 0; i < XR; ++i) {
             const int t2 = xt[i] + dt, h2 = xh[i] * a.stride + dh, w2 = xw[i] * a.stride + dw;
             const bool ok = xvalid[i] && (unsigned)t2 < (unsigned)a.T && (unsigned)h2 < (unsigned)a.Hin &&
                             (unsigned)w2 < (unsigned)a.Win;
-            const unsigned off = ok ? (unsigned)(((t2 * a.Hin + h2) * a.Win + w2) * ld + coff) * ESZ : FLAIR_OOB;
+            const unsigned off = ok ? (unsigned)((((t2 - fb) * a.Hin + h2) * a.Win + w2) * ld + coff) * ESZ : FLAIR_OOB;
             xreg[i] = buf_load16(xr, off);
         }
         const unsigned kofs = (unsigned)(tap * a.CinTot + segOff + coff) * ESZ;
@@ -1017,9 +1028,12 @@ extern "C" int flair_conv_nhwc(const flair_conv_params* p, const void* const* x,
         a.segC[i] = p->seg_c[i];
         a.segLd[i] = p->seg_ld[i];
         a.CinTot += p->seg_c[i];
-        const unsigned long long bytes =
-            (((unsigned long long)p->T * p->H * p->W - 1) * p->seg_ld[i] + p->seg_c[i]) * esz;   // input pixels
-        FLAIR_CHECK(bytes < 0x80000000ull, "flair_conv_nhwc: segment %d spans %llu bytes (limit 2 GiB)", i, bytes);
+        // buffer resources cover single frames (halo kernels) or the few frames a pixel tile spans
+        // (im2col kernels: at most 2 frames of this size), never the whole clip: only ONE FRAME has to
+        // stay below 1 GiB
+        const unsigned long long bytes = (unsigned long long)p->H * p->W * p->seg_ld[i] * esz;   // one input frame
+        FLAIR_CHECK(bytes < 0x40000000ull, "flair_conv_nhwc: one frame of segment %d spans %llu bytes (limit 1 GiB)",
+                    i, bytes);
         a.segBytes[i] = (unsigned)bytes;
     }
     {

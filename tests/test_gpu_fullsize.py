@@ -145,3 +145,29 @@ def test_full_forward_repeatable_and_bf16_tracks_f32(dev):
     yf = mf(x, t, **kw).float()
     err = (y1 - yf).abs().max().item()
     assert err <= 5e-2 * yf.abs().max().item(), (err, yf.abs().max().item())
+
+
+def test_conv_on_clips_larger_than_2gib(dev):
+    """Config 5 (32 frames x 512^2) feeds conv inputs beyond the 2 GiB one buffer resource addresses:
+    a delta filter must copy the selected channel / neighbouring frame exactly, also in the last frame."""
+    ops = _ops()
+    Tb, Hb, Wb, C = 5, 1024, 1024, 256                      # 2.7 GB in bf16
+    x = torch.randn(Tb, Hb, Wb, C, device=dev, dtype=torch.bfloat16)
+    assert x.numel() * 2 > 2 ** 31
+    k = 37
+    # 3x3 halo kernel: centre tap selects channel k
+    w = torch.zeros(8, C, 1, 3, 3)
+    w[2, k, 0, 1, 1] = 1.0
+    y = ops.conv(x, ops.pack_conv_weight(w, [(C, C)], torch.bfloat16).to(dev), None, 8, (1, 3, 3))
+    assert torch.equal(y[..., 2], x[..., k]) and not y[..., 3].any()
+    # 3x3x3: the tap at dt=+1, dh=-1 reads the next frame one row up (zero beyond the clip / image)
+    w3 = torch.zeros(8, C, 3, 3, 3)
+    w3[5, k, 2, 0, 1] = 1.0
+    y3 = ops.conv(x, ops.pack_conv_weight(w3, [(C, C)], torch.bfloat16).to(dev), None, 8, (3, 3, 3))
+    assert torch.equal(y3[:-1, 1:, :, 5], x[1:, :-1, :, k])
+    assert not y3[-1, :, :, 5].any() and not y3[:, 0, :, 5].any()
+    # 1x1 (im2col kernel)
+    w1 = torch.zeros(8, C, 1, 1, 1)
+    w1[7, k, 0, 0, 0] = -2.0
+    y1 = ops.conv(x, ops.pack_conv_weight(w1, [(C, C)], torch.bfloat16).to(dev), None, 8, (1, 1, 1))
+    assert torch.equal(y1[..., 7], -2.0 * x[..., k])
