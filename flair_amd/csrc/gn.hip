@@ -195,7 +195,23 @@ __global__ void gn_apply_kernel(GnApply a) {
         const long per = (n + a.blocksPerFrame - 1) / a.blocksPerFrame;
         long end = (blk + 1) * per;
         if (end > n) end = n;
-        for (long p = blk * per + r; p < end; p += rows) {
+        // y never aliases x (header contract): keep 4 loads in flight before the first store
+        long p = blk * per + r;
+        for (; p + 3 * rows < end; p += 4 * rows) {
+            uint4 raw4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                raw4[u] = *reinterpret_cast<const uint4*>(base + (fin + p + (long)u * rows) * ld);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float v[VEC];
+                Vec16<E>::load(reinterpret_cast<const E*>(&raw4[u]), v);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) v[i] = apply_act(fmaf(v[i], A[i], B[i]), a.act);
+                Vec16<E>::store(y + (fin + p + (long)u * rows) * a.yLd + c0, v);
+            }
+        }
+        for (; p < end; p += rows) {
             float v[VEC];
             Vec16<E>::load(base + (fin + p) * ld, v);
 #pragma unroll
@@ -331,7 +347,7 @@ extern "C" int flair_groupnorm_nhwc(const flair_gn_params* p, const void* x0, co
     a.act = p->act; a.resample = p->resample;
     a.y = y; a.yLd = p->y_ld; a.raw = raw; a.rawLd = p->raw_ld;
     const long outPix = p->resample == 1 ? (long)p->H * p->W / 4 : (long)p->H * p->W;
-    int bpf = (int)((outPix + (long)rows * 8 - 1) / ((long)rows * 8));
+    int bpf = (int)((outPix + (long)rows * 4 - 1) / ((long)rows * 4));
     const int maxBpf = 4096 / p->F > 0 ? 4096 / p->F : 1;
     if (bpf > maxBpf) bpf = maxBpf;
     if (bpf < 1) bpf = 1;

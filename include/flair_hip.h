@@ -126,6 +126,7 @@ typedef struct {
     int film_ld;
 } flair_gn_params;
 
+/* y (and raw) must not alias x0 / x1. */
 size_t flair_groupnorm_workspace_bytes(const flair_gn_params* p);
 int flair_groupnorm_nhwc(const flair_gn_params* p, const void* x0, const void* x1,
                          const float* gamma, const float* beta, const float* film, void* y,
