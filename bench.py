@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--task", default="gaussian", choices=["gaussian", "jpeg", "x8_bicubic", "x16_bicubic"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay a captured hipGraph of the UNet forward instead of launching eagerly "
+                         "(measured: no gain, the step is GPU-bound; profiles/README.md)")
     return ap.parse_args()
 
 
@@ -121,6 +124,9 @@ def main():
     t_bcast = parallel.broadcast_weights(model, src=0) if world > 1 else 0.0
     if a.dtype == "bf16":
         model.convert_to_fp16()
+    use_graph = a.graph and hasattr(model, "enable_hip_graph")
+    if use_graph:
+        model.enable_hip_graph()          # one hipGraph per clip shape: ~3300 launches become one replay
     clip_id = rank                                     # weak scaling: one clip per GPU
     degraded, init, rnn = (v.to(dev) for v in wl.clip_inputs(a.task, clip_id, T, S))
     lr_flat = degraded[0].contiguous()
@@ -180,6 +186,8 @@ def main():
     finite = bool(torch.isfinite(out["sample"]).all().item())
 
     # ---- roofline leg: one more step with every conv launch bracketed by HIP events ------
+    if use_graph:
+        model.enable_hip_graph(False)     # the instrumented step launches eagerly (events around each conv)
     ops.CONV_PROFILE = []
     next(gen)
     torch.cuda.synchronize()
@@ -220,7 +228,8 @@ def main():
                                   "unet_new.UNetModel 405.6M params random init, blur x4 restore_fn on GPU")
                                + ", one clip per GPU",
                    "steps_per_clip": TOTAL_STEPS, "value_definition": f"n_gpus*frames/({TOTAL_STEPS}*mean timed step)",
-                   "finite_output": finite, "weight_broadcast_s": t_bcast},
+                   "finite_output": finite, "weight_broadcast_s": t_bcast,
+                   "hip_graph": use_graph},
         "roofline": {"bound": "mfma", "kernel": CONV_VARIANTS.get(key[0], str(key[0])) + " " + key[1],
                      "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                      "traffic": None, "launches": calls, "avg_launch_us": 1e6 * secs / calls,
