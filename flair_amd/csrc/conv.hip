@@ -51,10 +51,20 @@ struct ConvArgs {
     int splitK;
     const float* fbias;    // optional per-(frame, channel) bias [T][fbiasLd] (emb added to h)
     int fbiasLd;
-    int debug;             // timing experiments only (FLAIR_CONV_DEBUG): 1 skip MFMA, 2 skip reloads
+    int debug;             // phase-timing switches, compiled in only with -DFLAIR_TIMING_SWITCHES (see FLAIR_DBG)
     int stride;            // spatial stride (1 or 2; im2col path only)
     int Hin, Win;          // input frame size (== H, W when stride == 1); H, W, P describe the OUTPUT
 };
+
+// Phase-timing switches of the halo kernel (how profiles/README.md's dissection was measured):
+// 1 skip the MFMA phase, 2 skip the in-loop reloads, 3/4/5 return before the first fetch / after
+// the first staged chunk / before the epilogue.  A build without -DFLAIR_TIMING_SWITCHES (the
+// product build) compiles them out: FLAIR_DBG is the constant 0 and the environment is not read.
+#ifdef FLAIR_TIMING_SWITCHES
+#define FLAIR_DBG(a) ((a).debug)
+#else
+#define FLAIR_DBG(a) 0
+#endif
 
 template <typename E> struct Mma;
 
@@ -308,7 +318,7 @@ void conv3x3_halo_kernel(ConvArgs a) {
     // software pipeline: chunk kk is multiplied out of LDS while chunks kk+1 .. kk+PF are in
     // flight in registers (set kk % PF holds chunk kk until it has been written to LDS)
     int issued = 0;
-    if (a.debug == 3) return;
+    if (FLAIR_DBG(a) == 3) return;
 #pragma unroll
     for (int s_ = 0; s_ < PF; ++s_)
         if (issued < nch) {
@@ -318,18 +328,18 @@ void conv3x3_halo_kernel(ConvArgs a) {
         }
     write_lds(hreg[0], wreg[0]);
     __syncthreads();
-    if (a.debug == 4) return;
+    if (FLAIR_DBG(a) == 4) return;
     for (int k = 0; k < nch; k += PF) {
 #pragma unroll
         for (int par = 0; par < PF; ++par) {
             const int kk = k + par;
             if (kk < nch) {
                 if (issued < nch) {       // set `par` went to LDS already: refill it
-                    if (a.debug != 2) issue(hreg[par], wreg[par]);
+                    if (FLAIR_DBG(a) != 2) issue(hreg[par], wreg[par]);
                     advance();
                     ++issued;
                 }
-                if (a.debug != 1) compute();
+                if (FLAIR_DBG(a) != 1) compute();
                 if (kk + 1 < nch) {
                     __syncthreads();      // everyone is done reading the staged chunk
                     write_lds(hreg[(par + 1) % PF], wreg[(par + 1) % PF]);
@@ -339,7 +349,7 @@ void conv3x3_halo_kernel(ConvArgs a) {
         }
     }
 
-    if (a.debug == 5) return;
+    if (FLAIR_DBG(a) == 5) return;
     // ---- epilogue.  The accumulator layout gives each lane 4 channels of one pixel (8-byte
     // pieces scattered over 32 pixels per store).  Transpose each wave's 32 x 64 tile through LDS
     // (staged as f32, so bias / activation / residuals stay exact) and let consecutive lanes
@@ -1068,10 +1078,13 @@ extern "C" int flair_conv_nhwc(const flair_conv_params* p, const void* const* x,
     FLAIR_CHECK(a.stride == 1 || a.stride == 2, "flair_conv_nhwc: stride %d unsupported", p->stride);
     a.part = nullptr;
     a.splitK = 1;
+    a.debug = 0;
+#ifdef FLAIR_TIMING_SWITCHES
     {
         static const int dbg = getenv("FLAIR_CONV_DEBUG") ? atoi(getenv("FLAIR_CONV_DEBUG")) : 0;
         a.debug = dbg;
     }
+#endif
     if (workspace && workspace_bytes >= flair_conv_workspace_bytes(p) && flair_conv_workspace_bytes(p) > 0) {
         FLAIR_CHECK(((uintptr_t)workspace) % 16 == 0, "flair_conv_nhwc: workspace alignment");
         a.part = reinterpret_cast<float*>(workspace);
