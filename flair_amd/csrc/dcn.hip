@@ -97,8 +97,14 @@ __global__ __launch_bounds__(32 * NPF * TPP, (NCF >= 4 ? 32 * NPF * TPP / 256 : 
     constexpr int VEC = ET<E>::VEC;
     constexpr unsigned ESZ = sizeof(E);
     constexpr int BKE = CPR * VEC;                            // K elements per step
-    constexpr int PAIRS = NCF * NPF / NW;                     // (cout-frag, pixel-frag) pairs per wave
-    static_assert(PAIRS * NW == NCF * NPF && PAIRS >= 1, "tile shape");
+    // (cout-frag, pixel-frag) pairs per wave; with more waves than pairs, KSPLIT waves share a pair and
+    // each multiplies its slice of the step's 64-byte K sub-steps (summed through LDS at the end)
+    constexpr int NPAIR = NCF * NPF;
+    constexpr int KSPLIT = NW > NPAIR ? NW / NPAIR : 1;
+    constexpr int PAIRS = NW > NPAIR ? 1 : NPAIR / NW;
+    constexpr int KSUB = CPR / 4 / KSPLIT;                    // K sub-steps per wave and step
+    static_assert((NW > NPAIR ? NPAIR * KSPLIT == NW : PAIRS * NW == NPAIR) && KSUB >= 1 && KSUB * KSPLIT * 4 == CPR,
+                  "tile shape");
     constexpr int WR = (TC * CPR + NT - 1) / NT;              // weight pieces per thread
     constexpr int RAWR = (TP * 3 * (int)ESZ + NT - 1) / NT;   // raw pieces per thread and tap (G <= 16)
     constexpr int BUF = (TC + TP) * CPR * 16;
@@ -262,10 +268,12 @@ __global__ __launch_bounds__(32 * NPF * TPP, (NCF >= 4 ? 32 * NPF * TPP / 256 : 
             const char* xb = wb + TC * CPR * 16;
 #pragma unroll
             for (int i = 0; i < PAIRS; ++i) {
-                const int pair = wave * PAIRS + i;
+                const int pair = KSPLIT > 1 ? wave % NPAIR : wave * PAIRS + i;
+                const int kpart = KSPLIT > 1 ? wave / NPAIR : 0;
                 const int pfrag = pair % NPF, cf = pair / NPF;
 #pragma unroll
-                for (int ks = 0; ks < CPR / 4; ++ks) {
+                for (int kk = 0; kk < KSUB; ++kk) {
+                    const int ks = kpart * KSUB + kk;
                     uint4 af[2], bf[2];
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
@@ -283,10 +291,33 @@ __global__ __launch_bounds__(32 * NPF * TPP, (NCF >= 4 ? 32 * NPF * TPP / 256 : 
             }
         }
     }
+    if constexpr (KSPLIT > 1) {
+        // sum the K slices of each pair: slices 1.. park their accumulators in LDS, slice 0 adds them
+        __syncthreads();                                   // the last step's tile reads are done
+        float* red = reinterpret_cast<float*>(stile);
+        const int pair0 = wave % NPAIR, kpart0 = wave / NPAIR;
+        if (kpart0 > 0) {
+            float* dst = red + ((kpart0 - 1) * NPAIR + pair0) * 64 * 16 + lane * 16;
+#pragma unroll
+            for (int r = 0; r < 16; r += 4)
+                *reinterpret_cast<float4*>(dst + r) = make_float4(acc[0][r], acc[0][r + 1], acc[0][r + 2], acc[0][r + 3]);
+        }
+        __syncthreads();
+        if (kpart0 > 0) return;
+#pragma unroll
+        for (int kp = 1; kp < KSPLIT; ++kp) {
+            const float* src = red + ((kp - 1) * NPAIR + pair0) * 64 * 16 + lane * 16;
+#pragma unroll
+            for (int r = 0; r < 16; r += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(src + r);
+                acc[0][r] += v.x; acc[0][r + 1] += v.y; acc[0][r + 2] += v.z; acc[0][r + 3] += v.w;
+            }
+        }
+    }
     E* y = reinterpret_cast<E*>(a.y);
 #pragma unroll
     for (int i = 0; i < PAIRS; ++i) {
-        const int pair = wave * PAIRS + i;
+        const int pair = KSPLIT > 1 ? wave % NPAIR : wave * PAIRS + i;
         const int pfrag = pair % NPF, cf = pair / NPF;
         const long po = p0 + pfrag * 32 + lr;
         if (po >= a.P) continue;
@@ -335,7 +366,7 @@ extern "C" int flair_dcn_align(const flair_dcn_params* p, const void* x0, const 
     FLAIR_CHECK(p && x0 && x1 && raw && w && y, "flair_dcn_align: null argument");
     FLAIR_CHECK(p->dtype == FLAIR_F32 || p->dtype == FLAIR_BF16, "flair_dcn_align: bad dtype");
     const int vec = p->dtype == FLAIR_BF16 ? 8 : 4;
-    const int bke = vec * (p->Cout <= 64 ? 4 : 8);      // K elements per step of the chosen tile
+    const int bke = vec * (p->Cout <= 64 && p->dtype != FLAIR_BF16 ? 4 : 8);      // K elements per step of the chosen tile
     const int esz = p->dtype == FLAIR_BF16 ? 2 : 4;
     const int cpg = p->G > 0 ? p->Cin / p->G : 0;
     FLAIR_CHECK(p->G > 0 && p->G % 8 == 0 && p->G <= 16 && p->Cin % p->G == 0 && cpg % vec == 0 &&
@@ -356,9 +387,10 @@ extern "C" int flair_dcn_align(const flair_dcn_params* p, const void* x0, const 
     FLAIR_CHECK(b0 < 0x80000000ull && b1 < 0x80000000ull && br < 0x80000000ull, "flair_dcn_align: tensor spans >= 2 GiB");
     a.xBytes[0] = (unsigned)b0; a.xBytes[1] = (unsigned)b1; a.rawBytes = (unsigned)((br + 15) / 16 * 16);
     a.wBytes = (unsigned)((unsigned long long)p->Cout * 9 * p->Cin * esz);
-    // Tile choice (measured on per-frame 256^2 / 128^2 calls, profiles/README.md): 64-pixel x 64-cout
-    // tiles with 4 threads per pixel for c=64, 32-pixel x 128-cout tiles with 8 threads per pixel above.
+    // Tile choice (measured on per-frame 256^2 / 128^2 calls, profiles/README.md).  c=64: 64 pixels x 64
+    // couts with 8 threads per pixel, so one gather instruction fetches the whole 128-byte channel row of a
+    // corner (two waves share each MFMA pair, K split); c=128: 32 pixels x 128 couts, 8 threads per pixel.
     if (p->dtype == FLAIR_BF16)
-        return p->Cout <= 64 ? launch_dcn<bf16_t, 2, 2, 4>(a, stream) : launch_dcn<bf16_t, 4, 1, 8>(a, stream);
+        return p->Cout <= 64 ? launch_dcn<bf16_t, 2, 2, 8>(a, stream) : launch_dcn<bf16_t, 4, 1, 8>(a, stream);
     return p->Cout <= 64 ? launch_dcn<float, 2, 2, 4>(a, stream) : launch_dcn<float, 4, 1, 8>(a, stream);
 }
