@@ -131,3 +131,26 @@ def test_hip_graph_replay_matches_eager(dev):
         torch.cuda.synchronize()
         assert torch.equal(y, ref)
     m.enable_hip_graph(False)
+
+
+def test_reference_checkpoint_ingest(tmp_path):
+    """CPU: a reference-format checkpoint file (fp32 state dict with the reference's keys) loads through the
+    safe loader; wrong files are refused."""
+    from flair_amd.checkpoint import load_reference_checkpoint
+    o, m = build_pair(SMALL, seed=5)
+    path = tmp_path / "flair_gaussian.pt"
+    torch.save(o.state_dict(), path)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.zero_()
+    rep = load_reference_checkpoint(m, str(path))
+    assert not rep.missing_keys and not rep.unexpected_keys
+    so, sm = o.state_dict(), m.state_dict()
+    assert all(torch.equal(so[k], sm[k]) for k in so)
+    wrapped = tmp_path / "wrapped.pt"
+    torch.save({"params_ema": o.state_dict()}, wrapped)
+    load_reference_checkpoint(m, str(wrapped))
+    bad = tmp_path / "bad.pt"
+    torch.save({"a": 1}, bad)
+    with pytest.raises(ValueError):
+        load_reference_checkpoint(m, str(bad))
