@@ -43,6 +43,8 @@ def _ops():
     # K-split halo kernel: launches of exactly 256 workgroups (one 256^2 / 128^2 frame)
     (1, 256, 256, [64, 32], 64, (1, 3, 3), 2, 2),
     (4, 64, 64, [64], 128, (3, 3, 3), 0, 1),
+    (1, 250, 256, [64], 64, (1, 3, 3), 3, 1),       # last row of tiles hangs over the image
+    (1, 125, 128, [32], 128, (1, 3, 3), 0, 0),
 ])
 def test_conv(dev, dtype, case):
     ops = _ops()
