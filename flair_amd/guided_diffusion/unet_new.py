@@ -465,6 +465,8 @@ class SPyNet(nn.Module):
         """ref, supp: (F,h,w,4) f32 normalised frames (channel 3 zero) -> (F,h,w,2) flow."""
         F_, h0, w0, _ = ref.shape
         dev = ref.device
+        if F_ == 0:               # a single-frame clip has no frame pairs
+            return torch.zeros((0, h0, w0, 2), dtype=torch.float32, device=dev)
         h = h0 if h0 % 32 == 0 else 32 * (h0 // 32 + 1)
         w = w0 if w0 % 32 == 0 else 32 * (w0 // 32 + 1)
         if (h, w) != (h0, w0):
@@ -695,6 +697,9 @@ class UNetModel(nn.Module):
         return self._flows_from_clip(raw)
 
     def _flows_from_clip(self, raw):
+        if raw.shape[0] < 2:      # a single frame has no neighbour: empty flow stacks, nothing to propagate
+            empty = torch.zeros((0, raw.shape[1], raw.shape[2], 2), dtype=torch.float32, device=raw.device)
+            return empty, empty
         pk = self.spynet._pk
         norm = torch.zeros_like(raw)
         ops.affine_channels(raw, 3, 0.5, 0.5, 0.0, 1.0, pk["mean"], pk["istd"], norm)

@@ -154,3 +154,20 @@ def test_reference_checkpoint_ingest(tmp_path):
     torch.save({"a": 1}, bad)
     with pytest.raises(ValueError):
         load_reference_checkpoint(m, str(bad))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,S", [(1, 32), (2, 32), (3, 48), (2, 40)])
+def test_unet_edge_shapes_vs_oracle(dev, T, S):
+    """Single-frame clip (no propagation), two frames (first-order only), sides that are not a multiple
+    of 32 (3x3 convs fall back to the im2col kernel, SPyNet resizes to a multiple of 32): f32 kernels."""
+    cfg = dict(SMALL, image_size=S)
+    o, m = build_pair(cfg, seed=2)
+    x, lr, t = _inputs(T, S, seed=11)
+    with torch.no_grad():
+        ref = o(x, t, low_res_input=lr, num_frames=T, vsrpp_weights=1.0)
+    m = m.to(dev)
+    y = m(x.to(dev), t.to(dev), low_res_input=lr.to(dev), num_frames=T, vsrpp_weights=1.0)
+    torch.cuda.synchronize()
+    err = (y.cpu() - ref).abs().max().item() / ref.abs().max().item()
+    assert err <= 2e-4, err
