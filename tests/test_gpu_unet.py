@@ -171,3 +171,29 @@ def test_unet_edge_shapes_vs_oracle(dev, T, S):
     torch.cuda.synchronize()
     err = (y.cpu() - ref).abs().max().item() / ref.abs().max().item()
     assert err <= 2e-4, err
+
+
+@pytest.mark.gpu
+def test_unet_call_variants_vs_oracle(dev):
+    """Two clips in one call (B=2), per-pixel vsrpp weights, rnn_input different from low_res_input, and
+    enable_cross_frames=False: the argument handling of unet_new.py:1311-1362, f32 kernels."""
+    o, m = build_pair(SMALL, seed=4)
+    m = m.to(dev)
+    T, S, B = 3, 32, 2
+    xs, lrs, rnns = [], [], []
+    for b in range(B):
+        x, lr, t = _inputs(T, S, seed=20 + b)
+        _, rnn, _ = _inputs(T, S, seed=40 + b)
+        xs.append(x); lrs.append(lr); rnns.append(rnn)
+    x, lr, rnn = torch.cat(xs), torch.cat(lrs), torch.cat(rnns)
+    t = torch.tensor([371] * T + [48] * T)
+    g = torch.Generator().manual_seed(1)
+    vw = 0.8 + 0.2 * torch.rand(B, T, 1, S, S, generator=g)
+    for kw in (dict(vsrpp_weights=vw, rnn_input=rnn), dict(vsrpp_weights=1.0, enable_cross_frames=False)):
+        with torch.no_grad():
+            ref = o(x, t, low_res_input=lr, num_frames=T, **kw)
+        kd = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in kw.items()}
+        y = m(x.to(dev), t.to(dev), low_res_input=lr.to(dev), num_frames=T, **kd)
+        torch.cuda.synchronize()
+        err = (y.cpu() - ref).abs().max().item() / ref.abs().max().item()
+        assert err <= 2e-4, (list(kw), err)
