@@ -147,3 +147,39 @@ def test_resizer_vs_golden(dev):
     up = Resizer(low.shape, 8)(low.to(dev))
     assert np.abs(down.cpu().numpy() - g["resizer_down8"]).max() <= 1e-5
     assert np.abs(up.cpu().numpy() - g["resizer_up8"]).max() <= 1e-5
+
+
+@pytest.mark.parametrize("learned", [True, False])
+def test_p_mean_variance_moments(dev, learned):
+    """p_mean_variance's full dict (gaussian_diffusion.py:250-342): pred_xstart, posterior mean and the
+    LEARNED_RANGE / FIXED_SMALL variance, against the formulas evaluated with the oracle's tables."""
+    from flair_amd.guided_diffusion.script_util import create_gaussian_diffusion
+    from oracle import diffusion as odiff
+    steps, i = 20, 7
+    d = create_gaussian_diffusion(diffusion_steps=1000, learn_sigma=learned, noise_schedule="face_blur",
+                                  timestep_respacing=str(steps), rescale_learned_sigmas=True)
+    tab = odiff.Spaced(odiff.spaced_steps(1000, str(steps)), odiff.named_betas("face_blur", 1000))
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(3, 3, 16, 16, generator=g)
+    out_c = 6 if learned else 3
+    mo = torch.randn(3, out_c, 16, 16, generator=g)
+    t = torch.full((3,), i, dtype=torch.long)
+
+    class M:
+        def __call__(self, xx, tt, **kw):
+            return mo.to(dev)
+    got = d.p_mean_variance(M(), x.to(dev), t.to(dev), clip_denoised=True, model_kwargs={})
+    f = lambda a: float(np.float32(a[i]))      # noqa: E731  (the reference extracts f32 table entries)
+    eps = mo[:, :3]
+    x0 = (f(tab.sqrt_recip_alphas_cumprod) * x - f(tab.sqrt_recipm1_alphas_cumprod) * eps).clamp(-1, 1)
+    mean = f(tab.posterior_mean_coef1) * x0 + f(tab.posterior_mean_coef2) * x
+    if learned:
+        frac = (mo[:, 3:] + 1) / 2
+        logvar = frac * float(np.float32(np.log(tab.betas[i]))) + (1 - frac) * f(tab.posterior_log_variance_clipped)
+        var = torch.exp(logvar)
+    else:
+        var = torch.full_like(x, f(tab.posterior_variance))
+        logvar = torch.full_like(x, f(tab.posterior_log_variance_clipped))
+    for name, ref in (("pred_xstart", x0), ("mean", mean), ("variance", var), ("log_variance", logvar)):
+        err = (got[name].cpu() - ref).abs().max().item()
+        assert err <= 2e-5 * max(1.0, ref.abs().max().item()), (name, err)
