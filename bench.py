@@ -74,14 +74,18 @@ def cpu_baseline(size, frames_sample=2, sample_size=128):
     lr = torch.rand(1, T, 3, sample_size, sample_size, generator=g) * 2 - 1
     t = torch.full((T,), 500, dtype=torch.long)
     build = time.time() - t0
-    t0 = time.time()
+    runs = []
     with torch.no_grad():
-        o(x, t, low_res_input=lr, num_frames=T, vsrpp_weights=1.0)
-    dt = time.time() - t0
+        for _ in range(2):                 # the first call also pays one-time primitive setup: keep the faster
+            t0 = time.time()
+            o(x, t, low_res_input=lr, num_frames=T, vsrpp_weights=1.0)
+            runs.append(time.time() - t0)
+    dt = min(runs)
     area = (size / sample_size) ** 2
     return {"value": T / (TOTAL_STEPS * dt * area), "unit": "frames/s", "cores": n_threads, "kind": "port",
             "sample": f"oracle/unet.py fp32 (torch CPU), 1 denoising step (UNet forward incl. SPyNet) of {T} "
-                      f"frames at {sample_size}x{sample_size}: {dt:.1f} s (model build {build:.0f} s); scaled to "
+                      f"frames at {sample_size}x{sample_size}: {dt:.1f} s (faster of 2 runs: "
+                      f"{', '.join(f'{r:.1f}' for r in runs)} s; model build {build:.0f} s); scaled to "
                       f"{size}x{size} by pixel count (x{area:.0f}) and to the {TOTAL_STEPS}-step job"}
 
 
