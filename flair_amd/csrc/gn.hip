@@ -309,8 +309,8 @@ extern "C" int flair_groupnorm_nhwc(const flair_gn_params* p, const void* x0, co
     FLAIR_CHECK(p->resample >= 0 && p->resample <= 2, "flair_groupnorm_nhwc: resample mode");
     FLAIR_CHECK(p->resample != 1 || (p->H % 2 == 0 && p->W % 2 == 0), "flair_groupnorm_nhwc: odd size for pooling");
     const int cv = C / vec;
-    FLAIR_CHECK(cv <= 256, "flair_groupnorm_nhwc: C=%d too wide", C);
-    const int rows = 256 / cv;
+    FLAIR_CHECK(cv <= 1024, "flair_groupnorm_nhwc: C=%d too wide", C);
+    const int rows = cv <= 256 ? 256 / cv : 1;      // wide tensors: one pixel row per workgroup of cv threads
     const int threads = rows * cv;
     const int nstat = p->F / p->frames_per_stat;
     const long pix = (long)p->frames_per_stat * p->H * p->W;

@@ -97,6 +97,7 @@ def test_conv_cases_cover_every_kernel_variant():
     (2, 8, 8, 256, 0, False, 2, None),
     (4, 8, 8, 96, 0, True, 0, 1),
     (16, 4, 4, 1024, 0, True, 0, None),
+    (3, 4, 4, 1024, 1024, True, 0, None),          # 2048 channels: more 16-byte slots than 256 threads in f32
 ])
 def test_group_norm(dev, dtype, case):
     ops = _ops()
