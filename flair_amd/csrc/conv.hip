@@ -450,11 +450,11 @@ int launch_halo(const ConvArgs& a0, hipStream_t s) {
 // K-split halo kernel for launches of at most one workgroup per CU (the per-frame convolutions of
 // the BasicVSR++ recurrence): same TH x 32 px x 64 cout tile and staging as above, but a wavefront
 // owns RPW image rows x 64 couts x ONE 16-channel half of the K step (wave = row group + k-half *
-// TH/RPW), so the tile is spread over twice the wavefronts per row group: the serial MFMA chain of
-// a chunk halves (and with RPW = 2 the weight fragments are reused across two rows: 1.0
-// ds_read_b128 per MFMA instead of 1.5 -- the loop above is bound by LDS bandwidth, not by the
-// matrix cores).  The two k-halves of a tile are summed through the LDS staging tile of the
-// epilogue.  Two LDS stages (one barrier per chunk), one workgroup per CU (up to 146 KB of LDS,
+// TH/RPW), so the tile is spread over twice the wavefronts per row group and the serial MFMA chain
+// of a chunk halves: with one workgroup per CU nothing else hides the staging phases, and more
+// resident waves do (measured: -10..-20 % per launch; the register tile shape itself does not
+// matter, tools/probes/lds_mfma_probe.hip).  The two k-halves of a tile are summed through the
+// LDS staging tile of the epilogue.  Two LDS stages (one barrier per chunk), one workgroup per CU (up to 146 KB of LDS,
 // 256 VGPRs).  Needs Cout % 8 == 0.
 template <typename E, int TH, int RPW, int CF>
 __global__ __launch_bounds__(256 * TH / RPW / CF, (256 * TH / RPW / CF) / 256) void conv3x3_halo_ks_kernel(ConvArgs a) {
