@@ -89,12 +89,40 @@ def cpu_baseline(size, frames_sample=2, sample_size=128):
                       f"{size}x{size} by pixel count (x{area:.0f}) and to the {TOTAL_STEPS}-step job"}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N rank processes (one per GPU) from this
+    process, which has not touched the GPU, and relay rank 0's JSON line.  Children get the same
+    environment torch.distributed.run would give them."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(c) for c in codes)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        n_dev = torch.cuda.device_count()       # counting devices does not initialise the GPU runtime
+        if n_dev < a.gpus:
+            raise SystemExit(f"--gpus {a.gpus} requested but only {n_dev} GPU(s) are visible")
+        raise SystemExit(spawn_ranks(a.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
+    if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)

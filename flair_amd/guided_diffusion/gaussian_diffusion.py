@@ -112,6 +112,18 @@ class GaussianDiffusion:
                          float(np.float32(self.sqrt_alphas_cumprod[i])),
                          float(np.float32(self.sqrt_one_minus_alphas_cumprod[i])))
 
+    def q_posterior_mean_variance(self, x_start, x_t, t):
+        """Mean / variance / clipped log-variance of q(x_{t-1} | x_t, x_0)
+        (gaussian_diffusion.py:226-248); uniform t."""
+        assert x_start.shape == x_t.shape
+        i = _uniform_step(t)
+        f32 = lambda v: float(np.float32(v))  # noqa: E731
+        mean = ops.axpby(x_start.float().contiguous(), x_t.float().contiguous(),
+                         f32(self.posterior_mean_coef1[i]), f32(self.posterior_mean_coef2[i]))
+        var = th.full_like(mean, f32(self.posterior_variance[i]))
+        logvar = th.full_like(mean, f32(self.posterior_log_variance_clipped[i]))
+        return mean, var, logvar
+
     def _scale_timesteps(self, t):
         if self.rescale_timesteps:
             return t.float() * (1000.0 / self.num_timesteps)
@@ -156,7 +168,24 @@ class GaussianDiffusion:
             out["variance"], out["log_variance"] = var, logvar
         return out
 
+    def _predict_xstart_from_eps(self, x_t, t, eps):
+        """sqrt(1/acp_t) x_t - sqrt(1/acp_t - 1) eps (gaussian_diffusion.py:344-349); uniform t."""
+        assert x_t.shape == eps.shape
+        i = _uniform_step(t)
+        return ops.axpby(x_t.float().contiguous(), eps.float().contiguous(),
+                         float(np.float32(self.sqrt_recip_alphas_cumprod[i])),
+                         -float(np.float32(self.sqrt_recipm1_alphas_cumprod[i])))
+
+    def _predict_xstart_from_xprev(self, x_t, t, xprev):
+        """(xprev - coef2 x_t) / coef1 (gaussian_diffusion.py:351-360); uniform t."""
+        assert x_t.shape == xprev.shape
+        i = _uniform_step(t)
+        return ops.axpby(xprev.float().contiguous(), x_t.float().contiguous(),
+                         float(np.float32(1.0 / self.posterior_mean_coef1[i])),
+                         -float(np.float32(self.posterior_mean_coef2[i] / self.posterior_mean_coef1[i])))
+
     def _predict_eps_from_xstart(self, x_t, t, pred_xstart):
+        """gaussian_diffusion.py:362-366; uniform t."""
         i = _uniform_step(t)
         a = float(np.float32(self.sqrt_recip_alphas_cumprod[i]))
         b = float(np.float32(self.sqrt_recipm1_alphas_cumprod[i]))
@@ -178,13 +207,17 @@ class GaussianDiffusion:
         if restore_fn is not None:
             restored = restore_fn(x0).float().contiguous()
         aux = None
+        # the reference compares against whatever the loop passed (gaussian_diffusion.py:473-474) and
+        # fails on its own default None; a direct call without it means "the prior is on from the start"
+        if start_timestep is None:
+            start_timestep = self.num_timesteps - 1
+        if tau is None:
+            tau = 0
         if aux_model is not None and i <= start_timestep and i >= tau:
             if not aligned:
-                aux_face = face_restore_helper.get_crop_face_from_affine_matrices(x0, affine_matrices)
-                aux_xt = face_restore_helper.get_crop_face_from_affine_matrices(x, affine_matrices)
                 raise NotImplementedError(
-                    "flair_amd: un-aligned face crop/paste (facelib) is outside the hot path; "
-                    "pass aligned=True")
+                    "flair_amd: un-aligned face crop/paste (facelib, gaussian_diffusion.py:476-493) is "
+                    "outside the hot path; pass aligned=True")
             # NB: the reference evaluates the aux prior on the data-consistent x0; the fused
             # kernel applies consistency + blend in one pass, so materialise that x0 first.
             if restored is not None:
@@ -302,6 +335,11 @@ class GaussianDiffusion:
                              "start_timestep unbound without one, gaussian_diffusion.py:632-680)")
         start_timestep = indices[0]
         ws, gammas = self.schedules(start_timestep, tau, w, zeta, noise_level)
+        # optical flow is cached per conditioning clip for the length of ONE chain: a caller may refill the
+        # same rnn_input storage through kernels that do not bump torch's version counter
+        inner = getattr(model, "model", model)
+        if hasattr(inner, "reset_flow_cache"):
+            inner.reset_flow_cache()
         if progress:
             from tqdm.auto import tqdm
             indices = tqdm(indices)

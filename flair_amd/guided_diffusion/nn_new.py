@@ -49,3 +49,47 @@ def zero_module(module):
 def timestep_embedding(timesteps, dim, max_period=10000):
     """Sinusoidal embeddings (nn_new.py:103-121) on the GPU; timesteps: 1-D device tensor."""
     return ops.timestep_embedding(timesteps.float().contiguous(), dim, float(max_period))
+
+
+class SiLU(nn.SiLU):
+    """nn_new.py:12-14 (layout marker: the activation is fused into the GroupNorm / conv kernels)."""
+
+
+class AvgPool2x2(nn.Module):
+    """What ``avg_pool_nd(2, kernel_size=2, stride=2)`` returns here: a marker whose ``run``
+    executes the 2x2 average pool of ``flair_resize_nhwc`` on an NHWC clip tensor."""
+
+    def __init__(self, kernel_size=2, stride=None):
+        super().__init__()
+        stride = kernel_size if stride is None else stride
+        if (kernel_size, stride) not in ((2, 2), ((2, 2), (2, 2))):
+            raise NotImplementedError("flair_amd: only the 2x2 / stride-2 average pool FLAIR uses is implemented")
+
+    def run(self, x):
+        T, H, W, _ = x.shape
+        return ops.resize(x, (H // 2, W // 2), ops.RESIZE_AVGPOOL2)
+
+    def forward(self, x):  # pragma: no cover - never on the product path
+        raise RuntimeError("flair_amd layers are executed by the HIP engine, not by torch")
+
+
+def avg_pool_nd(dims, *args, **kwargs):
+    """nn_new.py:42-52.  FLAIR only builds the 2-D 2x2 pool (unet_new.py:186-191)."""
+    if dims == 2:
+        return AvgPool2x2(*args, **kwargs)
+    raise ValueError(f"flair_amd: avg_pool_nd supports dims=2 only (got {dims})")
+
+
+def scale_module(module, scale):
+    """nn_new.py:77-83."""
+    for p in module.parameters():
+        p.detach().mul_(scale)
+    return module
+
+
+def checkpoint(func, inputs, params, flag):
+    """nn_new.py:124-140.  Gradient checkpointing trades backward-pass memory for recompute; this
+    package only samples (no autograd graph is ever built), so both settings of ``flag`` evaluate
+    ``func(*inputs)`` exactly as the reference's ``CheckpointFunction.forward`` does under
+    ``no_grad`` (nn_new.py:142-150)."""
+    return func(*inputs)

@@ -395,6 +395,10 @@ class UNet(nn.Module):
         self._packed_key = key
         self._flow_cache = {}
 
+    def reset_flow_cache(self):
+        """Forget cached SPyNet flows (called by the sampler at the start of every chain)."""
+        self._flow_cache = {}
+
     # ---- flows: once per (clip, resolution) ----------------------------------------------
     def _flows_for(self, rnn_clip, resolutions):
         key = (rnn_clip.data_ptr(), rnn_clip._version, tuple(rnn_clip.shape))

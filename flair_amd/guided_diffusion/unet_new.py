@@ -639,7 +639,10 @@ class UNetModel(nn.Module):
         return out
 
     def reset_flow_cache(self):
+        """Forget cached SPyNet flows (the sampler calls this at the start of every chain: flows are a
+        function of the conditioning clip, which only changes between chains)."""
         self._flow_cache = {}
+        self._flow_gen = getattr(self, "_flow_gen", 0) + 1
 
     # ---- weight packing ---------------------------------------------------------------
     def _res_blocks(self):
@@ -757,46 +760,49 @@ class UNetModel(nn.Module):
     def _forward_clip_graphed(self, x, t, low_res, rnn, enable_cross_frames, vsrpp_weights):
         key = (tuple(x.shape), self.dtype, bool(enable_cross_frames), vsrpp_weights, x.device)
         ent = self._graphs.get(key)
-        src = (rnn.data_ptr(), rnn._version, low_res.data_ptr(), low_res._version)
+        # conditioning identity: storage + torch version + the sampler's chain counter (kernels launched
+        # through ctypes do not bump _version, so every new chain refreshes conditioning and flows once)
+        src = (rnn.data_ptr(), rnn._version, low_res.data_ptr(), low_res._version, getattr(self, "_flow_gen", 0))
         if ent is None:
             st = dict(x=x.clone(), t=t.clone(), lr=low_res.clone(), rnn=rnn.clone())
-            self._flows_for(st["rnn"])                       # SPyNet runs eagerly, before capture
+            flows = self._flows_for(st["rnn"])               # SPyNet runs eagerly, before capture
             cur = torch.cuda.current_stream()
             side = torch.cuda.Stream()
             side.wait_stream(cur)
             with torch.cuda.stream(side):                    # warm-up (allocator, workspaces)
-                self._forward_clip(st["x"], st["t"], st["lr"], st["rnn"], enable_cross_frames, vsrpp_weights)
+                self._forward_clip(st["x"], st["t"], st["lr"], st["rnn"], enable_cross_frames, vsrpp_weights,
+                                   flows=flows)
             cur.wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 out = self._forward_clip(st["x"], st["t"], st["lr"], st["rnn"], enable_cross_frames,
-                                         vsrpp_weights)
-            ent = dict(graph=graph, st=st, out=out, src=src)
+                                         vsrpp_weights, flows=flows)
+            ent = dict(graph=graph, st=st, out=out, src=src, flows=flows)
             self._graphs[key] = ent
         st = ent["st"]
-        if ent["src"] != src:                                # a new clip: refresh conditioning + flows
-            old = self._flows_for(st["rnn"])
+        if ent["src"] != src:                                # a new clip / chain: refresh conditioning + flows
             st["lr"].copy_(low_res)
             st["rnn"].copy_(rnn)
-            new = self._flows_for(st["rnn"])                 # version bumped -> recomputed
-            for r in old:                                    # the graph holds the old flow buffers
-                for o, n in zip(old[r], new[r]):
-                    o.copy_(n)
-            self._flow_cache[(st["rnn"].data_ptr(), st["rnn"]._version, tuple(st["rnn"].shape))] = (old, st["rnn"])
+            self._flow_cache.pop((st["rnn"].data_ptr(), st["rnn"]._version, tuple(st["rnn"].shape)), None)
+            new = self._flows_for(st["rnn"])
+            for r, pair in ent["flows"].items():             # the graph reads the flow buffers it captured
+                for o, n in zip(pair, new[r]):
+                    if o is not n:
+                        o.copy_(n)
             ent["src"] = src
         st["x"].copy_(x)
         st["t"].copy_(t)
         ent["graph"].replay()
         return ent["out"]
 
-    def _forward_clip(self, x, t, low_res, rnn, enable_cross_frames, vsrpp_weights):
+    def _forward_clip(self, x, t, low_res, rnn, enable_cross_frames, vsrpp_weights, flows=None):
         T, _, H, W = x.shape
         dev, dt = x.device, self.dtype
         ctx = Ctx(dt, dev, T)
         ctx.enable_cross_frames = enable_cross_frames
         ctx.vsrpp_weights = vsrpp_weights
-        ctx.flows = self._flows_for(rnn)
+        ctx.flows = flows if flows is not None else self._flows_for(rnn)
         # timestep embedding MLP and every emb_layers linear of the network (f32)
         temb = ops.timestep_embedding(t.float().contiguous(), self.model_channels)
         e = ops.linear(temb, self._te[0], self._te[1], act_out=A.ACT_SILU)

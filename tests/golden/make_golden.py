@@ -51,9 +51,137 @@ class ToyModule(torch.nn.Module):
         return toy_model(x, t, **kw)
 
 
+def h16(t):
+    """Round through fp16 so a fixture input can be stored in half the bytes and still be exact."""
+    return t.half().float()
+
+
+def g4_blocks():
+    """G4: per-block inputs / outputs of the reference's own block classes, weights from
+    parameter names.  Inputs are stored as fp16 (the values are fp16-exact), outputs as f32."""
+    import refimport
+    un = refimport.ref("unet_new")
+    sr3 = refimport.ref("sr3")
+    unet_old = refimport.ref("unet_old")
+    out = {}
+
+    def seeded(name):
+        return torch.Generator().manual_seed(zlib.crc32(name.encode()))
+
+    def run(name, block, shape, emb_dim=512, with_emb=True, call=None):
+        g = seeded(name)
+        x = h16(torch.randn(1, *shape, generator=g))
+        emb = h16(torch.randn(shape[0], emb_dim, generator=g)) if with_emb else None
+        name_seeded_weights(block)
+        block.eval()
+        y = call(block, x, emb) if call else (block(x, emb) if with_emb else block(x))
+        out[name + "_x"] = x.half()
+        if emb is not None:
+            out[name + "_emb"] = emb.half()
+        out[name + "_y"] = y.float()
+
+    R = lambda cin, cout, **kw: un.ResBlock(cin, 512, 0.0, out_channels=cout, use_scale_shift_norm=True, **kw)  # noqa: E731
+    run("res2d_same", R(64, 64), (2, 64, 32, 32))
+    run("res2d_skip", R(128, 64), (2, 128, 16, 16))
+    run("res2d_up", R(64, 64, up=True), (2, 64, 16, 16))
+    run("res2d_down", R(64, 64, down=True), (2, 64, 32, 32))
+    run("res3d", un.TemporalWrapper(R(64, 64, dims=3)), (4, 64, 16, 16))
+    run("attn_legacy", un.AttentionBlock(128, num_head_channels=64), (2, 128, 16, 16), with_emb=False)
+    run("attn_new", un.AttentionBlock(128, num_head_channels=64, use_new_attention_order=True), (2, 128, 16, 16),
+        with_emb=False)
+    run("attn_bottle", un.AttentionbottleBlock(512, num_head_channels=64), (2, 512, 4, 4))
+    run("tattn", un.TemporalWrapper(un.TemporalAttention(128, 5, num_head_channels=64)), (6, 128, 8, 8),
+        with_emb=False)
+    # raw attention functions from the stub-free unet_old (qkv: (N, 3*H*C, L))
+    g = seeded("qkv")
+    qkv = h16(torch.randn(3, 3 * 2 * 64, 64, generator=g))
+    out["qkv_x"] = qkv.half()
+    out["qkv_legacy_y"] = unet_old.QKVAttentionLegacy(2)(qkv)
+    out["qkv_new_y"] = unet_old.QKVAttention(2)(qkv)
+
+    # deformable alignment and one BasicVSR++ instance (c = 64, 32x32: the halo-conv geometry)
+    def smooth_flow(g, n, h, w, mag):
+        f = torch.randn(n, 2, h // 8, w // 8, generator=g) * mag
+        return h16(torch.nn.functional.interpolate(f, size=(h, w), mode="bilinear", align_corners=False))
+
+    with refimport.cuda_shaped():
+        vs = un.BasicVSRPP(mid_channels=64)
+    name_seeded_weights(vs)
+    vs.eval()
+    al = vs.deform_align["backward_1"]
+    g = seeded("align")
+    c, S = 64, 32
+    x = h16(torch.randn(1, 2 * c, S, S, generator=g))
+    extra = h16(torch.randn(1, 3 * c, S, S, generator=g))
+    f1, f2 = smooth_flow(g, 1, S, S, 2.0), smooth_flow(g, 1, S, S, 3.0)
+    out.update(align_x=x.half(), align_extra=extra.half(), align_flow1=f1.half(), align_flow2=f2.half(),
+               align_y=al(x, extra, f1, f2).float())
+    g = seeded("vsrpp")
+    T = 4
+    hid = h16(torch.randn(1, T, c, S, S, generator=g))
+    ff = smooth_flow(g, T - 1, S, S, 1.5)[None]
+    fb = smooth_flow(g, T - 1, S, S, 1.5)[None]
+    out.update(vsrpp_x=hid.half(), vsrpp_ff=ff.half(), vsrpp_fb=fb.half(),
+               vsrpp_y=vs(hid, ff, fb, 0.93).float())
+    wmap = h16(torch.rand(1, T, 1, 16, 16, generator=g))
+    out.update(vsrpp_wmap=wmap.half(), vsrpp_wmap_y=vs(hid, ff, fb, wmap).float())
+
+    # sr3 block: ResnetBlock + (3,1,1) temporal ResBlock + 7-frame temporal attention, both emb-gated
+    blk = sr3.ResnetBlocWithAttn(64, 128, noise_level_emb_dim=64, norm_groups=16, conv_3d=True, temporal_attn=True,
+                                 num_frames=7, head_dim=64)
+    run("sr3_block", blk, (5, 64, 16, 16), emb_dim=64, call=lambda b, x, e: b(x, None, e))
+    save("g4_blocks", **out)
+
+
+def g8_blur_forward():
+    """pseudoSR forward operator A (pseudoSR.py:283-295, reflect padding) on a seeded image."""
+    import scipy.io
+    import refimport
+    ps = refimport.ref("pseudoSR")
+    K = scipy.io.loadmat(os.path.join(refimport.REFERENCE_ROOT, "miscs", "kernels_12.mat"))["kernels"][0, 3]
+    A = ps.pseudoSR(ps.Get_pseudoSR_Conf(4), upscale_kernel=K, kernel_indx=10).WrapArchitecture_PyTorch()
+    x = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(8))
+    save("g8_blur_forward", x=x, y=A.A(x))
+
+
+def g5_unet_64():
+    """G5 at 64x64x4: the SMALL network at image_size 64 -- final output and three stages."""
+    import refimport
+    un = refimport.ref("unet_new")
+    cfg = dict(SMALL, image_size=64)
+    with refimport.cuda_shaped():
+        model = un.UNetModel(**cfg)
+    name_seeded_weights(model)
+    model.eval()
+    T, S = 4, 64
+    gen = torch.Generator().manual_seed(64)
+    x = h16(torch.randn(T, 3, S, S, generator=gen))
+    base = torch.rand(3, S, S, generator=gen) * 2 - 1
+    lr = torch.stack([torch.roll(base, shifts=(i, 2 * i), dims=(1, 2)) for i in range(T)])[None]
+    lr = h16((lr + 0.05 * torch.randn(1, T, 3, S, S, generator=gen)).clamp(-1, 1))
+    t = torch.full((T,), 123, dtype=torch.long)
+    stages = {}
+    for nm, b in (("input_blocks.2", model.input_blocks[2]), ("middle_block", model.middle_block),
+                  ("output_blocks.4", model.output_blocks[4])):
+        b.register_forward_hook(lambda mod, inp, o, nm=nm: stages.__setitem__(nm, o[0]))
+    y = model(x, t, low_res_input=lr, num_frames=T, vsrpp_weights=1.0)
+    save("g5_unet_64", x=x.half(), lr=lr.half(), t=t, y=y,
+         **{"stage_" + k.replace(".", "_"): v.half() for k, v in stages.items()})
+
+
+EXTRA = {"g4": g4_blocks, "g8": g8_blur_forward, "g5_64": g5_unet_64}
+
+
 def main():
     import refimport
     refimport.install_stubs()
+    torch.set_grad_enabled(False)
+    only = sys.argv[1:]
+    for key, fn in EXTRA.items():
+        if not only or key in only:
+            fn()
+    if only and "base" not in only:
+        return
     gd = refimport.ref("gaussian_diffusion")
     rs = refimport.ref("respace")
     un = refimport.ref("unet_new")

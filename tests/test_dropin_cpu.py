@@ -1,0 +1,89 @@
+"""The package-level drop-in: after ``flair_amd.install_as_guided_diffusion()`` the import lines of
+the reference's ``scripts/video_sample.py`` (:11-15,27) bind to this package, and names this
+package does not implement (``guided_diffusion.codeformer``, ``guided_diffusion.facelib``, :17,28)
+still resolve to the reference's files when its checkout is supplied."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFERENCE = "/root/reference"
+
+# the guided_diffusion import statements of scripts/video_sample.py:11-15,27 (third-party imports dropped)
+SCRIPT_IMPORTS = """
+from guided_diffusion.gaussian_diffusion import ModelMeanType, ModelVarType, LossType, get_named_beta_schedule
+from guided_diffusion.respace import space_timesteps, SpacedDiffusion
+from guided_diffusion.sr3 import UNet as BicubicUNet
+from guided_diffusion.unet_new import UNetModel as BlurUNet
+import guided_diffusion.pseudoSR as pseudo_sr
+from guided_diffusion.restore_util import SRConv
+from guided_diffusion.jpeg import jpeg_decode, jpeg_encode
+"""
+
+
+def run(code):
+    r = subprocess.run([sys.executable, "-c", textwrap.dedent(code)], cwd=ROOT, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return r.stdout
+
+
+def test_script_imports_bind_to_flair_amd():
+    out = run(f"""
+        import flair_amd
+        flair_amd.install_as_guided_diffusion()
+        {SCRIPT_IMPORTS.replace(chr(10), chr(10) + '        ')}
+        # modules the model files of the reference import from each other (sr3.py:9-31, unet_new.py:10-19)
+        from guided_diffusion.unet import TemporalAttention, TemporalWrapper, ResBlock, BasicVSRPP
+        from guided_diffusion.nn import GroupNorm32, conv_nd, LazyReshaper2D, LazyReshaper3D, normalization, checkpoint, zero_module, linear, FalshAttn, timestep_embedding
+        from guided_diffusion.nn_new import checkpoint, conv_nd, linear, avg_pool_nd, zero_module, normalization, timestep_embedding
+        from guided_diffusion.script_util import create_model_and_diffusion, model_and_diffusion_defaults, add_dict_to_argparser, args_to_dict, str2bool
+        import guided_diffusion
+        for cls in (BicubicUNet, BlurUNet, SRConv, SpacedDiffusion):
+            assert cls.__module__.startswith("flair_amd.guided_diffusion."), cls.__module__
+        assert guided_diffusion.sr3.UNet is BicubicUNet
+        d = SpacedDiffusion(use_timesteps=space_timesteps(1000, "100", "uniform"),
+                            betas=get_named_beta_schedule("face_blur", 1000), model_mean_type=ModelMeanType.EPSILON,
+                            model_var_type=ModelVarType.LEARNED_RANGE, loss_type=LossType.RESCALED_MSE,
+                            rescale_timesteps=False)
+        assert d.num_timesteps == 100
+        for name in ("q_posterior_mean_variance", "_predict_xstart_from_eps", "_predict_eps_from_xstart",
+                     "p_mean_variance", "p_sample", "p_sample_loop", "p_sample_loop_progressive", "sample", "q_sample"):
+            assert callable(getattr(d, name)), name
+        print("ok")
+    """)
+    assert out.strip().endswith("ok")
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="needs the reference checkout (build container only)")
+def test_reference_only_modules_stay_importable():
+    out = run(f"""
+        import importlib.util
+        import flair_amd
+        flair_amd.install_as_guided_diffusion({REFERENCE!r})
+        {SCRIPT_IMPORTS.replace(chr(10), chr(10) + '        ')}
+        from guided_diffusion.codeformer import CodeFormer            # video_sample.py:17
+        assert CodeFormer.__module__ == "guided_diffusion.codeformer"
+        import guided_diffusion.codeformer as cf
+        assert cf.__file__.startswith({REFERENCE!r}), cf.__file__
+        spec = importlib.util.find_spec("guided_diffusion.facelib")    # video_sample.py:28 (needs cv2 to import)
+        assert spec is not None and any(p.startswith({REFERENCE!r}) for p in spec.submodule_search_locations)
+        assert BlurUNet.__module__ == "flair_amd.guided_diffusion.unet_new"
+        print("ok")
+    """)
+    assert out.strip().endswith("ok")
+
+
+def test_bench_refuses_gpus_it_cannot_see():
+    """`python bench.py --gpus N` without a launcher spawns N ranks itself; with fewer visible GPUs it
+    must fail loudly instead of reporting a 1-GPU number."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with < 2 GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "GPU(s) are visible" in (r.stderr + r.stdout)

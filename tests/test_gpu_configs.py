@@ -1,0 +1,265 @@
+"""One `-m gpu` test per BASELINE.json configuration, at that configuration's own geometry.
+
+  config 1  gaussian-demo, 8 frames x 128x128, 50-step chain, fp32: the REAL network
+            (blur_config(128), 405.6 M parameters) on the f32 kernels against the CPU oracle --
+            first UNet forward stage by stage, then two full sampler steps (UNet + blur restore_fn
+            + fused update) on a shared noise tape.  Tolerance 2e-4 of each stage's max magnitude
+            (BASELINE.md section 3 asks 1e-4 abs on [-1,1] data for the final sample: checked too).
+  config 2  gaussian-demo 16 x 256x256 bf16: tests/test_gpu_fullsize.py (properties) + one full-width
+            oracle forward here at a size the host can do (2 frames x 256x256 would take minutes:
+            the full-width network is compared at 128x128 in the config-1 test; here the 256x256
+            kernel variants -- halo convolution with 4096 workgroups, per-frame K-split kernel on a
+            256x256 frame, c = 64 alignment kernel -- run one real BasicVSR++ level against the oracle).
+  config 3  x8-bicubic-demo, sr3.UNet(image_size=256) 16 x 256x256: repeatable / finite / bf16 tracks
+            f32 at full size, and the real full-width sr3_config against the oracle at 4 x 128x128.
+  config 4  jpeg-demo per-GPU workload (16 x 256x256, blur + JPEG qf 60 restore_fn): two bf16 sampler
+            steps are finite and bit-repeatable; the JPEG operator itself is pinned in
+            tests/test_gpu_sampler.py.  The 8-GPU leg is clip-parallel with no data-path collective
+            (tests/test_parallel_cpu.py covers the partition and the weight broadcast on gloo).
+  config 5  x16-bicubic-demo, sr3.UNet(image_size=512) on 32 x 512x512: one forward, same properties.
+
+Everything that touches oracle/thirdparty.py (deform_conv2d, flow_warp, SPyNet, flash-attn) is
+**parity unpinned** in its internals (packages absent; restated from their published definitions).
+"""
+import pytest
+import torch
+
+from tests.util import from_clip
+
+pytestmark = pytest.mark.gpu
+
+
+def _hooks(o, stages):
+    def hook(name):
+        def f(mod, inp, out):
+            stages.append((name, out.detach()))
+        return f
+    hs = [b.register_forward_hook(hook(f"input_blocks.{i}")) for i, b in enumerate(o.input_blocks)]
+    hs.append(o.middle_block.register_forward_hook(hook("middle_block")))
+    hs += [b.register_forward_hook(hook(f"output_blocks.{i}")) for i, b in enumerate(o.output_blocks)]
+    return hs
+
+
+def test_config1_gaussian_8x128_f32_vs_oracle(dev):
+    from flair_amd import workload as wl
+    from flair_amd.guided_diffusion import pseudoSR as psr
+    from flair_amd.guided_diffusion.unet_new import UNetModel
+    from oracle import degrade as odeg
+    from oracle import diffusion as odiff
+    from oracle.unet import UNetModel as Oracle
+    T, S, STEPS = 8, 128, 50
+    cfg = wl.blur_config(S, use_fp16=False)
+    torch.manual_seed(0)
+    o = Oracle(**cfg).eval()
+    wl.randomize_zero_modules(o)
+    m = UNetModel(**cfg)
+    m.load_state_dict(o.state_dict(), strict=True)
+    m = m.to(dev).eval()
+    degraded, init, rnn = wl.clip_inputs("gaussian", 0, T, S)
+    hp = wl.TASKS["gaussian"]
+    kern = wl.synthetic_blur_kernel()
+    tab = odiff.Spaced(odiff.spaced_steps(1000, str(STEPS)), odiff.named_betas("face_blur", 1000))
+    g = torch.Generator().manual_seed(4321)
+    x_T = odiff.q_sample(tab, init[0], torch.full((T,), STEPS - 1), torch.randn(T, 3, S, S, generator=g))
+    tape = [torch.randn(T, 3, S, S, generator=g) for _ in range(2)]
+    oblur = odeg.BlurOperator(kern, 4)
+
+    # ---- oracle: two steps of the chain; the first forward's stages are recorded
+    stages, ref_trace, calls = [], [], []
+    hs = _hooks(o, stages)
+
+    class Stop(Exception):
+        pass
+
+    def omodel(x, t, **kw):
+        if len(calls) == 2:
+            raise Stop()
+        if len(calls) == 1:
+            for h in hs:
+                h.remove()
+        calls.append(1)
+        return o(x, t, **kw)
+    with torch.no_grad():
+        try:
+            odiff.sample_loop(tab, omodel, x_T,
+                              model_kwargs=dict(low_res_input=init, num_frames=T, rnn_input=rnn, vsrpp_weights=1.0),
+                              restore_fn=lambda x0: oblur.a_pinv(degraded[0], x0), aux_model=wl.identity_aux,
+                              w=hp["w"], tau=5, rho=hp["rho"], noise_level=hp["noise_level"], zeta=hp["zeta"],
+                              step_noise=tape + [tape[0]] * STEPS, trace=ref_trace)
+        except Stop:
+            pass
+    assert len(ref_trace) == 2
+
+    # ---- HIP: the same two steps through the product sampler
+    diffusion = wl.diffusion_for(STEPS)
+    A = psr.pseudoSR(psr.Get_pseudoSR_Conf(4), upscale_kernel=kern, kernel_indx=10).WrapArchitecture_PyTorch().to(dev)
+    lr_d = degraded[0].to(dev)
+    m._trace = []
+    gen = diffusion.p_sample_loop_progressive(
+        m, x_T.shape, noise=x_T.to(dev),
+        model_kwargs=dict(low_res_input=init.to(dev), num_frames=T, rnn_input=rnn.to(dev), vsrpp_weights=1.0),
+        device=dev, restore_fn=lambda x0: A.A_pinv(lr_d, x0), aux_model=wl.identity_aux, w=hp["w"], tau=5,
+        aligned=True, rho=hp["rho"], noise_level=hp["noise_level"], zeta=hp["zeta"],
+        noise_fn=lambda it, like: tape[it].to(dev))
+    out1 = next(gen)
+    trace1 = list(m._trace)
+    m._trace = None
+    out2 = next(gen)
+    torch.cuda.synchronize()
+
+    report = []
+    for (n1, a), (n2, b) in zip(stages, trace1):
+        assert n1 == n2
+        a4 = a[0].float()
+        report.append((n1, (from_clip(b) - a4).abs().max().item() / (a4.abs().max().item() + 1e-12)))
+    assert len(report) == len(stages) == 43
+    bad = [r for r in report if r[1] > 2e-4]
+    assert not bad, f"stages beyond 2e-4: {bad[:4]}"
+    for (ti, x0r, sr), got in zip(ref_trace, (out1, out2)):
+        assert int(got["t"][0]) == ti
+        assert (got["pred_xstart"].cpu() - x0r).abs().max().item() <= 1e-4, ti
+        assert (got["sample"].cpu() - sr).abs().max().item() <= 2e-4 * max(1.0, sr.abs().max().item()), ti
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_config2_vsrpp_level_at_256_vs_oracle(dev, dtype):
+    """One real BasicVSR++ level of config 2 (c = 64 on 256x256 frames, T = 3: first- and second-order
+    steps) against the oracle: the halo-convolution, per-frame K-split and c=64 alignment kernel
+    variants the headline bench spends its time in, at their bench geometry."""
+    from flair_amd.guided_diffusion import unet_new as hu
+    from oracle import unet as ou
+    from tests.golden.weights import name_seeded_weights
+    from tests.util import to_clip
+    T, S, c = 3, 256, 64
+    o = name_seeded_weights(ou.BasicVSRPP(c)).eval()
+    m = name_seeded_weights(hu.BasicVSRPP(mid_channels=c)).to(dev).eval()
+    g = torch.Generator().manual_seed(22)
+    hid = torch.randn(1, T, c, S, S, generator=g)
+    if dtype == torch.bfloat16:
+        hid = hid.bfloat16().float()
+
+    def flow(mag):
+        f = torch.randn(T - 1, 2, S // 16, S // 16, generator=g) * mag
+        return torch.nn.functional.interpolate(f, size=(S, S), mode="bilinear", align_corners=False)[None]
+    ff, fb = flow(2.0), flow(2.0)
+    with torch.no_grad():
+        ref = o(hid, ff, fb, 1.0)[0]
+    m.pack(dtype, dev)
+    ctx = hu.Ctx(dtype, dev, T)
+    nhwc = lambda f: f[0].permute(0, 2, 3, 1).contiguous().to(dev)      # noqa: E731
+    ctx.flows = {S: (nhwc(ff), nhwc(fb))}
+    ctx.vsrpp_weights = 1.0
+    y = m.run(ctx, to_clip(hid[0], dtype, dev))
+    torch.cuda.synchronize()
+    e = (from_clip(y) - ref).abs().max().item() / ref.abs().max().item()
+    assert e <= (2e-4 if dtype == torch.float32 else 4e-2), e
+
+
+def _sr3_model(S, dtype):
+    from flair_amd.guided_diffusion.sr3 import UNet
+    from flair_amd.workload import randomize_zero_modules, sr3_config
+    torch.manual_seed(0)
+    m = UNet(**sr3_config(S, use_fp16=(dtype == torch.bfloat16)))
+    randomize_zero_modules(m)
+    return m.eval()
+
+
+def _sr3_properties(dev, T, S, task):
+    from flair_amd import workload as wl
+    hp = wl.TASKS[task]
+    degraded, init, _ = wl.clip_inputs(task, 0, T, S)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(T, 3, S, S, generator=g).to(dev)
+    level = torch.full((T,), 0.61, device=dev)
+    kw = dict(low_res_input=init.to(dev), num_frames=T,
+              vsrpp_weights=wl.face_weight_map(T, S, hp["face_weight"]).to(dev))
+    mb = _sr3_model(S, torch.bfloat16).to(dev)
+    y1 = mb(x, level, **kw).float()
+    y2 = mb(x, level, **kw).float()
+    assert y1.shape == (T, 3, S, S)
+    assert torch.equal(y1, y2) and torch.isfinite(y1).all()
+    sd = mb.state_dict()
+    del mb
+    torch.cuda.empty_cache()
+    mf = _sr3_model(S, torch.float32)
+    mf.load_state_dict(sd)
+    mf = mf.to(dev)
+    yf = mf(x, level, **kw).float()
+    err = (y1 - yf).abs().max().item()
+    assert err <= 5e-2 * yf.abs().max().item(), (err, yf.abs().max().item())
+
+
+def test_config3_x8_bicubic_16x256_full_size(dev):
+    """sr3.UNet(image_size=256) (236 M parameters) on a 16 x 256x256 clip."""
+    _sr3_properties(dev, 16, 256, "x8_bicubic")
+
+
+def test_config5_x16_bicubic_32x512_full_size(dev):
+    """sr3.UNet(image_size=512) on a 32 x 512x512 clip (activations beyond 2 GiB per tensor)."""
+    _sr3_properties(dev, 32, 512, "x16_bicubic")
+
+
+def test_config3_sr3_full_width_vs_oracle_4x128(dev):
+    """The real sr3_config (inner 64, mults 1,2,4,8,16, BasicVSR++ at S and S/2, temporal attention at S/8,
+    S/16) at the largest size the host oracle does in about a minute: 4 frames x 128x128, f32 kernels."""
+    from flair_amd import workload as wl
+    from flair_amd.guided_diffusion.sr3 import UNet
+    from oracle.sr3 import UNet as Oracle
+    T, S = 4, 128
+    cfg = wl.sr3_config(S, use_fp16=False)
+    ocfg = dict(cfg)
+    torch.manual_seed(0)
+    o = Oracle(**ocfg).eval()
+    wl.randomize_zero_modules(o)
+    m = UNet(**cfg)
+    m.load_state_dict(o.state_dict(), strict=True)
+    m = m.to(dev).eval()
+    degraded, init, _ = wl.clip_inputs("x8_bicubic", 0, T, S)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(T, 3, S, S, generator=g)
+    level = torch.full((T,), 0.77)
+    vw = wl.face_weight_map(T, S, 0.93)
+    with torch.no_grad():
+        ref = o(x, level, low_res_input=init, num_frames=T, vsrpp_weights=vw)
+    y = m(x.to(dev), level.to(dev), low_res_input=init.to(dev), num_frames=T, vsrpp_weights=vw.to(dev))
+    torch.cuda.synchronize()
+    err = (y.cpu() - ref).abs().max().item() / ref.abs().max().item()
+    assert err <= 3e-4, err
+
+
+def test_config4_jpeg_16x256_two_steps(dev):
+    """jpeg-demo per-GPU workload: two bf16 sampler steps (UNet + blur/JPEG restore_fn + update) twice
+    from the same state: bit-identical and finite."""
+    from flair_amd import workload as wl
+    from flair_amd.guided_diffusion import pseudoSR as psr
+    from flair_amd.guided_diffusion.jpeg import jpeg_decode, jpeg_encode
+    from flair_amd.guided_diffusion.unet_new import UNetModel
+    T, S = 16, 256
+    hp = wl.TASKS["jpeg"]
+    torch.manual_seed(0)
+    m = UNetModel(**wl.blur_config(S, use_fp16=True))
+    wl.randomize_zero_modules(m)
+    m = m.to(dev).eval()
+    m.convert_to_fp16()
+    degraded, init, rnn = (v.to(dev) for v in wl.clip_inputs("jpeg", 0, T, S))
+    A = psr.pseudoSR(psr.Get_pseudoSR_Conf(4), upscale_kernel=wl.synthetic_blur_kernel(),
+                     kernel_indx=10).WrapArchitecture_PyTorch().to(dev)
+    qf = hp["jpeg_qf"]
+    lr = degraded[0].contiguous()
+    restore = lambda x0: A.A_pinv(lr, x0, jpeg_encode=lambda im: jpeg_encode(im, qf),      # noqa: E731
+                                  jpeg_decode=lambda im: jpeg_decode(im, qf))
+    diffusion = wl.diffusion_for(250)
+    g = torch.Generator(device=dev).manual_seed(1)
+    x_T = torch.randn(T, 3, S, S, device=dev, generator=g)
+    tape = [torch.randn(T, 3, S, S, device=dev, generator=g) for _ in range(2)]
+
+    def two_steps():
+        gen = diffusion.p_sample_loop_progressive(
+            m, x_T.shape, noise=x_T.clone(),
+            model_kwargs=dict(low_res_input=init, num_frames=T, rnn_input=rnn, vsrpp_weights=1.0), device=dev,
+            restore_fn=restore, aux_model=wl.identity_aux, w=hp["w"], tau=5, aligned=True, rho=hp["rho"],
+            noise_level=hp["noise_level"], zeta=hp["zeta"], noise_fn=lambda it, like: tape[it])
+        next(gen)
+        return next(gen)["sample"].clone()
+    a, b = two_steps(), two_steps()
+    assert torch.isfinite(a).all() and torch.equal(a, b)
