@@ -32,10 +32,34 @@ if ROOT not in sys.path:
 
 TOTAL_STEPS = 250
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+# rocprofv3 kernel names of the conv variants (keys of profiles/*_hbm_traffic_pmc.json)
+CONV_ROCPROF = {0: "conv_igemm_kernel<{E}, 128, 128, 2, 2>", 1: "conv_igemm_kernel<{E}, 64, 128, 1, 4>",
+                2: "conv_igemm_kernel<{E}, 64, 64, 2, 2>", 3: "conv3x3_halo_kernel<{E}, 8, 1, 1>",
+                4: "conv3x3_halo_kernel<{E}, 4, 1, 1>", 5: "conv3x3_halo_kernel<{E}, 2, 1, 1>",
+                6: "conv3x3_halo_ks_kernel<{E}, 8, 1, 2>", 7: "conv3x3_halo_ks_kernel<{E}, 4, 1, 2>"}
 CONV_VARIANTS = {0: "conv_igemm_kernel<128co x 128px>", 1: "conv_igemm_kernel<64co x 128px>",
                  2: "conv_igemm_kernel<64co x 64px>", 3: "conv3x3_halo_kernel<8 rows>",
                  4: "conv3x3_halo_kernel<4 rows>", 5: "conv3x3_halo_kernel<2 rows>",
                  6: "conv3x3_halo_ks_kernel<8 rows>", 7: "conv3x3_halo_ks_kernel<4 rows>"}
+
+
+def pmc_traffic_for(kernel_fmt, dkey):
+    """HBM bytes per launch of `kernel` from the newest committed PMC table (profiles/*_hbm_traffic_pmc.json,
+    written by tools/pmc_traffic.py from two separate rocprofv3 --pmc passes of this same command: counters
+    cannot be read from inside the process).  Returns (bytes or None, source file or None)."""
+    import glob
+    name = kernel_fmt.format(E="bf16" if dkey == "bf16" else "float")
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic_pmc.json")), reverse=True):
+        try:
+            with open(path) as f:
+                tab = json.load(f)
+        except (OSError, ValueError):
+            continue
+        ent = tab.get("kernels", {}).get(name)
+        if ent:
+            return ent["read_bytes_per_launch"] + ent["write_bytes_per_launch"], os.path.relpath(path, ROOT)
+    return None, None
 
 
 def parse():
@@ -56,37 +80,58 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(size, frames_sample=2, sample_size=128):
-    """Oracle (port) timed on the host: one UNet forward (= one denoising step's dominant cost) of
-    `frames_sample` frames at `sample_size`^2 with the same network; conv work is linear in the
-    pixel count, so frames/s at `size`^2 = frames / (250 steps * dt * (size/sample_size)^2)."""
+def cpu_baseline(size, frames):
+    """Oracle (port) timed on this host's cores on BASELINE config 1's own geometry: ONE full denoising step
+    (UNet forward incl. SPyNet + blur restore_fn + generalised-DDIM update) of the 8-frame 128x128 gaussian-demo
+    clip with the full-width network, fp32.  `value` converts that to the metric's unit for the benched job
+    (frames x size^2, TOTAL_STEPS steps): conv work is linear in frames x pixels."""
+    from flair_amd import workload as wl
+    from oracle import degrade as odeg
+    from oracle import diffusion as odiff
     from oracle.unet import UNetModel as Oracle
-    from flair_amd.workload import blur_config, randomize_zero_modules
+    T, S, STEPS = 8, 128, 50
     n_threads = torch.get_num_threads()
     torch.manual_seed(0)
-    cfg = blur_config(sample_size, use_fp16=False)
     t0 = time.time()
-    o = Oracle(**cfg).eval()
-    randomize_zero_modules(o)
-    T = frames_sample
-    g = torch.Generator().manual_seed(5)
-    x = torch.randn(T, 3, sample_size, sample_size, generator=g)
-    lr = torch.rand(1, T, 3, sample_size, sample_size, generator=g) * 2 - 1
-    t = torch.full((T,), 500, dtype=torch.long)
+    o = Oracle(**wl.blur_config(S, use_fp16=False)).eval()
+    wl.randomize_zero_modules(o)
     build = time.time() - t0
-    runs = []
+    degraded, init, rnn = wl.clip_inputs("gaussian", 0, T, S)
+    hp = wl.TASKS["gaussian"]
+    tab = odiff.Spaced(odiff.spaced_steps(1000, str(STEPS)), odiff.named_betas("face_blur", 1000))
+    g = torch.Generator().manual_seed(4321)
+    x_T = odiff.q_sample(tab, init[0], torch.full((T,), STEPS - 1), torch.randn(T, 3, S, S, generator=g))
+    z = torch.randn(T, 3, S, S, generator=g)
+    oblur = odeg.BlurOperator(wl.synthetic_blur_kernel(), 4)
+    calls = []
+
+    class Stop(Exception):
+        pass
+
+    def model(x, t, **kw):
+        if calls:
+            raise Stop()
+        calls.append(1)
+        return o(x, t, **kw)
+    trace = []
+    t0 = time.time()
     with torch.no_grad():
-        for _ in range(2):                 # the first call also pays one-time primitive setup: keep the faster
-            t0 = time.time()
-            o(x, t, low_res_input=lr, num_frames=T, vsrpp_weights=1.0)
-            runs.append(time.time() - t0)
-    dt = min(runs)
-    area = (size / sample_size) ** 2
-    return {"value": T / (TOTAL_STEPS * dt * area), "unit": "frames/s", "cores": n_threads, "kind": "port",
-            "sample": f"oracle/unet.py fp32 (torch CPU), 1 denoising step (UNet forward incl. SPyNet) of {T} "
-                      f"frames at {sample_size}x{sample_size}: {dt:.1f} s (faster of 2 runs: "
-                      f"{', '.join(f'{r:.1f}' for r in runs)} s; model build {build:.0f} s); scaled to "
-                      f"{size}x{size} by pixel count (x{area:.0f}) and to the {TOTAL_STEPS}-step job"}
+        try:
+            odiff.sample_loop(tab, model, x_T,
+                              model_kwargs=dict(low_res_input=init, num_frames=T, rnn_input=rnn, vsrpp_weights=1.0),
+                              restore_fn=lambda x0: oblur.a_pinv(degraded[0], x0), aux_model=wl.identity_aux,
+                              w=hp["w"], tau=5, rho=hp["rho"], noise_level=hp["noise_level"], zeta=hp["zeta"],
+                              step_noise=[z] * STEPS, trace=trace)
+        except Stop:
+            pass
+    dt = time.time() - t0                      # one full step (the second model call stops the loop at once)
+    scale = (frames / T) * (size / S) ** 2
+    return {"value": frames / (TOTAL_STEPS * dt * scale), "unit": "frames/s", "cores": n_threads, "kind": "port",
+            "config1_frames_per_s": T / (STEPS * dt),
+            "sample": f"oracle/ (torch CPU fp32, {n_threads} threads): ONE full denoising step of BASELINE config 1 "
+                      f"(gaussian-demo, {T} frames x {S}x{S}, full-width network): {dt:.1f} s (model build {build:.0f} s) "
+                      f"= {T / (STEPS * dt):.2e} frames/s for config 1's 50-step job; `value` scales the step by "
+                      f"frames x pixels (x{scale:.0f}) to the benched {frames} x {size}x{size}, {TOTAL_STEPS}-step job"}
 
 
 def spawn_ranks(n):
@@ -217,15 +262,14 @@ def main():
         elapsed = float(tmax.item())
     finite = bool(torch.isfinite(out["sample"]).all().item())
 
-    # ---- roofline leg: one more step with every conv launch bracketed by HIP events ------
+    # ---- roofline leg: one more step with every conv / GroupNorm / alignment / attention call bracketed by
+    # HIP events on the launch stream (an empty event pair is measured and subtracted)
     if use_graph:
-        model.enable_hip_graph(False)     # the instrumented step launches eagerly (events around each conv)
-    ops.CONV_PROFILE = []
+        model.enable_hip_graph(False)     # the instrumented step launches eagerly (events around each call)
+    ops.PROFILE = []
     next(gen)
     torch.cuda.synchronize()
-    prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
-    # an empty event pair still measures the record-to-record gap on the stream: calibrate it
-    # away so that the per-launch time is the kernel's own duration (agrees with rocprofv3)
+    prof, ops.PROFILE = ops.PROFILE, None
     gaps = []
     for _ in range(64):
         c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -235,18 +279,50 @@ def main():
     torch.cuda.synchronize()
     gap_ms = sorted(c0.elapsed_time(c1) for c0, c1 in gaps)[len(gaps) // 2]
     per = {}
-    for variant, dt_name, flops, e0, e1 in prof:
-        d = per.setdefault((variant, dt_name), [0, 0.0, 0.0])
+    for fam, dt_name, flops, nbytes, e0, e1 in prof:
+        d = per.setdefault((fam, dt_name), [0, 0.0, 0.0, 0.0])
         d[0] += 1
         d[1] += flops
-        d[2] += max(e0.elapsed_time(e1) - gap_ms, 1e-4) * 1e-3
-    key = max(per, key=lambda k: per[k][2])
-    calls, flops, secs = per[key]
+        d[2] += nbytes
+        d[3] += max(e0.elapsed_time(e1) - gap_ms, 1e-4) * 1e-3
+    conv_keys = [k for k in per if k[0][0] == "conv"]
+    key = max(conv_keys, key=lambda k: per[k][3])
+    calls, flops, _, secs = per[key]
     achieved = flops / secs / 1e12
-    peak = MFMA_PEAK_TFLOPS["bf16" if "bfloat16" in key[1] else "f32"]
-    all_flops = sum(v[1] for v in per.values())
-    all_secs = sum(v[2] for v in per.values())
+    dkey = "bf16" if "bfloat16" in key[1] else "f32"
+    peak = MFMA_PEAK_TFLOPS[dkey]
+    all_flops = sum(per[k][1] for k in conv_keys)
+    all_secs = sum(per[k][3] for k in conv_keys)
+    step_s = elapsed / K
 
+    def family(pred, bound, label):
+        ks = [k for k in per if pred(k[0])]
+        if not ks:
+            return None
+        n = sum(per[k][0] for k in ks)
+        fl, by, se = (sum(per[k][i] for k in ks) for i in (1, 2, 3))
+        ent = {"family": label, "bound": bound, "launches": n, "ms_per_step": 1e3 * se, "share_of_step": se / step_s}
+        if bound == "mfma":
+            pk = MFMA_PEAK_TFLOPS["bf16" if "bfloat16" in ks[0][1] else "f32"]
+            ent.update(achieved=fl / se / 1e12, peak=pk, unit="TFLOP/s", frac=fl / se / 1e12 / pk)
+        else:
+            ent.update(achieved=by / se / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=by / se / 1e9 / HBM_PEAK_GBS,
+                       algorithmic_MB_per_launch=by / n / 1e6)
+        return ent
+    fams = [
+        family(lambda f: f[0] == "conv" and f[1] in (6, 7), "mfma",
+               "per-frame 3x3 convs of the BasicVSR++ recurrence (conv3x3_halo_ks_kernel / fused chains)"),
+        family(lambda f: f[0] == "conv" and f[1] in (3, 4, 5), "mfma", "clip-level 3x3 / 3x3x3 convs + c->432 offset convs (conv3x3_halo_kernel)"),
+        family(lambda f: f[0] == "conv" and f[1] in (0, 1, 2), "mfma", "1x1 / strided / small-spatial convs (conv_igemm_kernel)"),
+        family(lambda f: f[0] == "chain", "mfma", "fused per-frame conv chains (conv_chain_kernel)"),
+        family(lambda f: f[0] == "gn", "hbm", "GroupNorm+SiLU+FiLM(+resample): gn_partial/finalize/apply, bytes = esz*3*numel"),
+        family(lambda f: f[0] == "dcn" and f[1] <= 64, "hbm", "deformable alignment c=64 (dcn_kernel), bytes = esz*(3c+432)*H*W"),
+        family(lambda f: f[0] == "dcn" and f[1] > 64, "hbm", "deformable alignment c=128 (dcn_kernel), bytes = esz*(3c+432)*H*W"),
+        family(lambda f: f[0] == "prep", "hbm", "flow warp + compose of one propagation step (vsrpp_prep_kernel)"),
+        family(lambda f: f[0] == "attn", "mfma", "spatial QKVAttention in situ (attn_mfma_bf16_kernel; isolated numbers: profiles/)"),
+    ]
+    fams = [f for f in fams if f]
+    traffic, traffic_src = pmc_traffic_for(CONV_ROCPROF.get(key[0][1], ""), dkey)
     ms_per_step = 1e3 * elapsed / K
     value = world * T / (TOTAL_STEPS * elapsed / K)
     line = {
@@ -262,16 +338,19 @@ def main():
                    "steps_per_clip": TOTAL_STEPS, "value_definition": f"n_gpus*frames/({TOTAL_STEPS}*mean timed step)",
                    "finite_output": finite, "weight_broadcast_s": t_bcast,
                    "hip_graph": use_graph},
-        "roofline": {"bound": "mfma", "kernel": CONV_VARIANTS.get(key[0], str(key[0])) + " " + key[1],
+        "roofline": {"bound": "mfma", "kernel": CONV_VARIANTS.get(key[0][1], str(key[0][1])) + " " + key[1],
                      "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                     "traffic": None, "launches": calls, "avg_launch_us": 1e6 * secs / calls,
+                     "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
+                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": per[key][2] / calls,
+                     "launches": calls, "avg_launch_us": 1e6 * secs / calls,
                      "all_conv_achieved": all_flops / all_secs / 1e12,
-                     "all_conv_share_of_step": all_secs / (ms_per_step * 1e-3)},
+                     "all_conv_share_of_step": all_secs / (ms_per_step * 1e-3),
+                     "families": fams},
     }
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             try:
-                line["cpu_baseline"] = cpu_baseline(S)
+                line["cpu_baseline"] = cpu_baseline(S, T)
             except Exception as exc:  # the baseline must never hide the measurement
                 line["cpu_baseline"] = {"value": None, "error": repr(exc)}
         print(json.dumps(line), flush=True)

@@ -124,24 +124,40 @@ def conv(xs, weight, bias, cout, kernel, *, out=None, act=ACT_NONE, res0=None, r
     p.act = act
     p.out_scale = out_scale
     assert weight.dtype == x0.dtype and weight.is_contiguous()
-    prof = CONV_PROFILE
-    if prof is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+    e0 = _prof_begin()
     wsb = _conv_ws_bytes(p)
     ws = _workspace(wsb, x0.device, "conv") if wsb else None
     check(lib().flair_conv_nhwc(ctypes.byref(p), arr, ptr(weight), ptr(_f32(bias)), ptr(frame_bias), ptr(res0),
                                 ptr(res1), ptr(out), ptr(ws), ctypes.c_size_t(wsb), stream()), "flair_conv_nhwc")
-    if prof is not None:
-        e1.record()
+    if e0 is not None:
         cin = sum(x.shape[3] for x in xs)
-        flops = 2.0 * T * Ho * Wo * cout * cin * kernel[0] * kernel[1] * kernel[2]
-        prof.append((lib().flair_conv_variant(ctypes.byref(p)), str(x0.dtype), flops, e0, e1))
+        taps = kernel[0] * kernel[1] * kernel[2]
+        esz = x0.element_size()
+        flops = 2.0 * T * Ho * Wo * cout * cin * taps
+        nbytes = esz * (cin * T * H * W + cout * T * Ho * Wo * (1 + (res0 is not None) + (res1 is not None))
+                        + cout * taps * cin)
+        _prof_end(e0, ("conv", lib().flair_conv_variant(ctypes.byref(p))), x0.dtype, flops, nbytes)
     return out
 
 
-# bench.py sets this to a list to time every conv launch with HIP events (roofline leg)
-CONV_PROFILE = None
+# bench.py sets PROFILE to a list to bracket every conv / GroupNorm / alignment / attention call with HIP
+# events on the launch stream (roofline leg): entries are (family, dtype name, algorithmic FLOPs,
+# algorithmic bytes, start event, end event).
+PROFILE = None
+
+
+def _prof_begin():
+    if PROFILE is None:
+        return None
+    e0 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    return e0
+
+
+def _prof_end(e0, family, dtype, flops, nbytes):
+    e1 = torch.cuda.Event(enable_timing=True)
+    e1.record()
+    PROFILE.append((family, str(dtype), float(flops), float(nbytes), e0, e1))
 
 
 def conv_variant(T, H, W, cins, cout, kernel, dtype=torch.bfloat16, stride=1):
@@ -234,9 +250,14 @@ def group_norm(x, gamma, beta, *, x1=None, groups=32, eps=1e-5, act=ACT_NONE, fi
     if film is not None:
         assert film.dtype == torch.float32 and film.stride(1) == 1 and film.shape[0] == T
     ws = _workspace(lib_ws_bytes(p), x.device)
+    e0 = _prof_begin()
     check(lib().flair_groupnorm_nhwc(ctypes.byref(p), ptr(x), ptr(x1), ptr(_f32(gamma)), ptr(_f32(beta)),
                                      ptr(film), ptr(out), ptr(raw), ptr(ws), stream()),
           "flair_groupnorm_nhwc")
+    if e0 is not None:   # two-pass GroupNorm: the input is read twice, the output written once
+        numel_in, numel_out = T * H * W * C, T * Ho * Wo * C
+        _prof_end(e0, ("gn",), x.dtype, 8.0 * numel_in,
+                  x.element_size() * (2 * numel_in + numel_out * (2 if want_raw else 1)))
     return (out, raw) if want_raw else out
 
 
@@ -305,7 +326,11 @@ def qkv_attention(qkv, heads, *, new_order=False, out=None):
     else:
         p.q_off, p.k_off, p.v_off, p.head_stride = 0, d, 2 * d, 3 * d
     p.scale = 1.0 / (d ** 0.5)
+    e0 = _prof_begin()
     check(lib().flair_qkv_attention(ctypes.byref(p), ptr(qkv), ptr(out), stream()), "flair_qkv_attention")
+    if e0 is not None:   # QK^T + AV: 4 * frames * heads * L^2 * d FLOPs; q, k, v read + out written
+        L = H * W
+        _prof_end(e0, ("attn", L), qkv.dtype, 4.0 * F_ * heads * L * L * d, qkv.element_size() * 4.0 * F_ * L * C)
     return out
 
 
@@ -391,8 +416,13 @@ def dcn_align(x0, x1, raw, flow1, flow2, weight, bias, cout, *, groups=16, max_m
         out = torch.empty((F_, H, W, cout), dtype=x0.dtype, device=x0.device)
     p.y_ld = _ld(out)
     p.max_residue_magnitude = max_mag
+    e0 = _prof_begin()
     check(lib().flair_dcn_align(ctypes.byref(p), ptr(x0), ptr(x1), ptr(raw), ptr(flow1), ptr(flow2), ptr(weight),
                                 ptr(_f32(bias)), ptr(out), stream()), "flair_dcn_align")
+    if e0 is not None:   # bytes = esz*(2c + 27G + c)*H*W; FLOPs = 2*9*2c*c*H*W + 9*2c*H*W*8
+        px = F_ * H * W
+        _prof_end(e0, ("dcn", cout), x0.dtype, px * (2.0 * 9 * 2 * ch * cout + 9.0 * 2 * ch * 8),
+                  x0.element_size() * px * (2 * ch + 27 * groups + cout))
     return out
 
 
@@ -532,11 +562,15 @@ def vsrpp_prep(prop, feat2, flow1, flow_prev, cond1, cond2, flow2_out, flowpad):
     prop/feat2/cond*: (1,H,W,c) clip tensors; flows: (1,H,W,2) f32; flowpad: (1,H,W,>=4)."""
     _, H, W, C = prop.shape
     second = flow_prev is not None
+    e0 = _prof_begin()
     check(lib().flair_vsrpp_prep(ptr(prop), _ld(prop), ptr(feat2 if second else None),
                                  _ld(feat2) if second else 0, ptr(_f32(flow1)), ptr(_f32(flow_prev)),
                                  dtype_code(prop), H, W, C, ptr(cond1), _ld(cond1), ptr(cond2 if second else None),
                                  _ld(cond2) if second else 0, ptr(flow2_out if second else None), ptr(flowpad),
                                  _ld(flowpad), stream()), "flair_vsrpp_prep")
+    if e0 is not None:   # reads 1-2 features, writes 1-2 warped features + the 4-channel flow pad
+        n = 2 if second else 1
+        _prof_end(e0, ("prep",), prop.dtype, 0.0, prop.element_size() * H * W * (2.0 * n * C + flowpad.shape[3]) + 8.0 * H * W * n)
 
 
 def gated_blend(x, m, gate, out=None):

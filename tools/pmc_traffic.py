@@ -2,7 +2,7 @@
 
     rocprofv3 --kernel-trace --pmc FETCH_SIZE -d <fetch_dir> -o b --output-format csv -- python bench.py ...
     rocprofv3 --kernel-trace --pmc WRITE_SIZE -d <write_dir> -o b --output-format csv -- python bench.py ...
-    python tools/pmc_traffic.py <fetch_dir> <write_dir>
+    python tools/pmc_traffic.py <fetch_dir> <write_dir> [out.json]
 
 FETCH_SIZE is doubled (gfx950 tallies 128-byte read requests at 64 bytes, MI355X_MICROARCH.md).
 """
@@ -45,8 +45,16 @@ def main():
         rows.append(((fetch + write) * calls, k, calls, fetch, write, dur))
     rows.sort(reverse=True)
     print(f"{'kernel':58s} {'calls':>6s} {'read MB':>9s} {'write MB':>9s} {'avg us':>8s} {'GB/s':>7s}")
-    for _, k, calls, fe, wr, dur in rows[:16]:
+    for _, k, calls, fe, wr, dur in rows[:20]:
         print(f"{k:58s} {calls:6d} {fe/1e6:9.2f} {wr/1e6:9.2f} {dur:8.1f} {(fe+wr)/dur/1e3:7.0f}")
+    if len(sys.argv) > 3:   # machine-readable copy (bench.py fills roofline.traffic from it)
+        import json
+        with open(sys.argv[3], "w") as fh:
+            json.dump({"command": "python bench.py --steps 2 --warmup 1 --no-cpu-baseline",
+                       "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes; "
+                                 "read = FETCH_SIZE*1024*2 (gfx950 correction), write = WRITE_SIZE*1024",
+                       "kernels": {k: {"launches": calls, "read_bytes_per_launch": fe, "write_bytes_per_launch": wr,
+                                       "avg_us": dur} for _, k, calls, fe, wr, dur in rows}}, fh, indent=1)
 
 
 if __name__ == "__main__":
