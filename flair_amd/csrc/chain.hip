@@ -1,0 +1,523 @@
+// Fused chains of 3x3 convolutions with the intermediate kept in LDS (halo recompute).
+//
+// The BasicVSR++ recurrence of the FLAIR UNet (guided_diffusion/unet_new.py:700-739,859-898) is a
+// chain of ~2 700 DEPENDENT per-frame launches per forward; a 64->64 convolution of one 256x256
+// frame is 2.7 us of matrix work inside ~12 us of launch / first fetch / write-back / drain
+// (profiles/README.md).  This kernel runs TWO consecutive 3x3 convolutions of such a chain in one
+// launch:
+//
+//   stage A (optional):  M = actA(conv3x3(cat(x[0..nseg)), WA) + biasA)       C channels, kept in LDS
+//   stage B:             Y = (actB(conv3x3(M, WB) + biasB) + res0 + res1) * out_scale   CoutB channels
+//
+// and, without stage A, a convolution whose whole input halo (all C channels) stays resident in LDS
+// while the workgroup walks the output channels in blocks of 64 (the c -> 27*G offset convolution:
+// the halo is staged once instead of once per 64 output channels).
+// Replaces, pairwise: conv_offset[2]+[4] / conv_offset[4]+[6] of SecondOrderDeformableAlignment
+// (unet_new.py:859-867) and conv1+conv2 of mmedit's ResidualBlockNoBN inside
+// ResidualBlocksWithInputConv (unet_new.py:659-668), including its two residual adds.
+//
+// A workgroup (8 wavefronts) owns a TH x TW output tile of one frame and ALL channels:
+//   * stage A computes the (TH+2) x (TW+2) intermediate tile (1.33x the pixels at 8 x 32) from a
+//     (TH+4) x (TW+4) input halo staged per 64-byte channel chunk (register prefetch of the next
+//     chunk, unconditional buffer loads -> hardware zero padding), and writes it to LDS in the
+//     element type (the same rounding point as the unfused pair), zeroing pixels outside the image
+//     (they are stage B's zero padding, not convolution outputs);
+//   * stage B reads its B operands straight from that LDS tile.
+// MFMA operand roles, the 80-byte LDS pitch (conflict-free ds_read_b128) and the tap loop are those of
+// conv3x3_halo_kernel (conv.hip); a work item is 32 pixels x 64 output channels on one wavefront.
+#include "common.h"
+
+namespace {
+
+struct ChainArgs {
+    const void* x[4];
+    int segC[4], segLd[4], nseg;
+    unsigned segBytes[4];
+    const void* wA; const float* biasA; int actA; int CinA; unsigned wABytes;
+    const void* wB; const float* biasB; int actB; int CoutB; unsigned wBBytes;
+    const void* res0; const void* res1; int res0Ld, res1Ld;
+    float outScale;
+    void* y; int yLd;
+    int T, H, W;
+    unsigned long long* dbg;   // probe build only (-DFLAIR_CHAIN_STAMPS): per-workgroup s_memtime stamps
+};
+
+// In-kernel phase stamps of the diagnostic build (tools/probes/chain_probe.py); the product build
+// compiles them out (no stamp executes, no argument is read).
+#ifdef FLAIR_CHAIN_STAMPS
+#include <stdlib.h>
+#define STAMP(k)                                                                           \
+    do {                                                                                   \
+        if (a.dbg && threadIdx.x == 0) a.dbg[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
+template <typename E> struct MmaC;
+template <> struct MmaC<bf16_t> {
+    static constexpr int BKE = 32;
+    static __device__ __forceinline__ int chunk(int i, int half) { return 2 * i + half; }
+    static __device__ __forceinline__ void run(const uint4 (&a)[2], const uint4 (&b)[2], f32x16& acc) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[0]),
+                                                      __builtin_bit_cast(bf16x8, b[0]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[1]),
+                                                      __builtin_bit_cast(bf16x8, b[1]), acc, 0, 0, 0);
+    }
+    static constexpr int MFMA_PER_STEP = 2;
+};
+template <> struct MmaC<float> {
+    static constexpr int BKE = 16;
+    static __device__ __forceinline__ int chunk(int i, int half) { return 2 * half + i; }
+    static __device__ __forceinline__ void run(const uint4 (&a)[2], const uint4 (&b)[2], f32x16& acc) {
+        const float* af = reinterpret_cast<const float*>(a);
+        const float* bf = reinterpret_cast<const float*>(b);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[s], acc, 0, 0, 0);
+    }
+    static constexpr int MFMA_PER_STEP = 8;
+};
+
+// activation of N values with ONE (wave-uniform) branch on the runtime code, not one per element
+template <int N>
+__device__ __forceinline__ void act_vec(float (&v)[N], int act) {
+    if (act == FLAIR_ACT_SILU) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) v[e] = silu_f(v[e]);
+    } else if (act != FLAIR_ACT_NONE) {
+        const float slope = act == FLAIR_ACT_RELU ? 0.f : 0.1f;      // max(v, slope * v) for slope in [0, 1)
+#pragma unroll
+        for (int e = 0; e < N; ++e) v[e] = fmaxf(v[e], v[e] * slope);
+    }
+}
+
+constexpr int CHAIN_MAX_COUTB = 512;   // stage-B biases are staged in LDS once
+
+template <typename E, int C, int TH, int TW, bool HASA>
+__global__ __launch_bounds__(512, 2) void conv_chain_kernel(ChainArgs a) {
+    constexpr int NT = 512, NW = 8;
+    constexpr int BKE = MmaC<E>::BKE;
+    constexpr int VEC = ET<E>::VEC;
+    constexpr unsigned ESZ = sizeof(E);
+    constexpr int PITCH = 80;
+    constexpr int WM = TW + 2, RM = TH + 2, NPM = RM * WM;           // intermediate (stage-B input) region
+    constexpr int WA = TW + 4, RA = TH + 4, NPA = RA * WA;           // stage-A input region
+    constexpr int NCH = C / BKE;                                     // channel chunks of the intermediate
+    constexpr int NB = C / 64;                                       // 64-cout blocks the weight buffer holds
+    constexpr int WROWS = 64 * NB;
+    constexpr int MID_BYTES = NCH * NPM * PITCH;
+    constexpr int W_BYTES = WROWS * 9 * PITCH;
+    constexpr int NGA = (NPM + 31) / 32, NITA = NGA * NB, MAXIA = (NITA + NW - 1) / NW;
+    constexpr int NGB = TH * TW / 32, NITB = NGB * NB, MAXIB = (NITB + NW - 1) / NW;
+    constexpr int IN_PIECES = (HASA ? NPA : NCH * NPM) * 4;          // 16-byte pieces per input staging
+    constexpr int HI = (IN_PIECES + NT - 1) / NT;
+    constexpr int W_PIECES = WROWS * 9 * 4;
+    constexpr int WI = (W_PIECES + NT - 1) / NT;
+    static_assert(TH * TW % 32 == 0 && C % 64 == 0, "tile");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* smid = smem;
+    char* sw = smem + MID_BYTES;
+    char* sin = sw + W_BYTES;                                        // only with stage A
+    float* sbias = reinterpret_cast<float*>(sin + (HASA ? NPA * PITCH : 0));   // [C] stage A | [CHAIN_MAX_COUTB] stage B
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int tilesW = a.W / TW, tilesH = (a.H + TH - 1) / TH;
+    const int perFrame = tilesW * tilesH;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int t = bid / perFrame;
+    const int tile = bid % perFrame;
+    const int h0 = (tile / tilesW) * TH, w0 = (tile % tilesW) * TW;
+    const long frameOff = (long)t * a.H * a.W;
+    STAMP(0);
+    // biases -> LDS once (a per-element global load in the epilogues would serialise on its latency)
+    for (int i = C + tid; i < C + CHAIN_MAX_COUTB; i += NT)
+        sbias[i] = (a.biasB && i - C < a.CoutB) ? a.biasB[i - C] : 0.f;
+
+    // ---- staging coordinates of the input region (stage-A halo, or the intermediate itself) -------
+    // piece id -> (chunk, pixel, 16-byte quarter); pixel -> frame pixel index or -1 (zero padding)
+    int ipix[HI], idst[HI];
+    unsigned iq[HI];
+#pragma unroll
+    for (int i = 0; i < HI; ++i) {
+        const int id = i * NT + tid;
+        constexpr int NP = HASA ? NPA : NPM, WR = HASA ? WA : WM, ORG = HASA ? 2 : 1;
+        const int pc = id >> 2;                   // (chunk, pixel) index
+        const int ch = HASA ? 0 : pc / NP;
+        const int pix = HASA ? pc : pc % NP;
+        const int r = pix / WR, c = pix % WR;
+        const int hh = h0 - ORG + r, ww = w0 - ORG + c;
+        const bool ok = id < IN_PIECES && (unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W;
+        ipix[i] = ok ? hh * a.W + ww : -1;
+        iq[i] = (unsigned)(ch * BKE + (id & 3) * VEC) * ESZ;     // byte offset inside the pixel's channels
+        idst[i] = id < IN_PIECES ? (ch * NP + pix) * PITCH + (id & 3) * 16 : -1;
+    }
+    uint4 hreg[HI], wreg[WI];
+
+    // K walk of stage A over (segment, chunk)
+    int seg = 0, cb = 0, segOff = 0;
+    auto issue_in = [&]() {
+        const unsigned ld = (unsigned)a.segLd[seg] * ESZ;
+        const char* frame = reinterpret_cast<const char*>(a.x[seg]) + (size_t)frameOff * ld;
+        const __amdgpu_buffer_rsrc_t xr = make_rsrc(frame, a.segBytes[seg]);
+        const unsigned cofs = (unsigned)(cb * BKE) * ESZ;
+#pragma unroll
+        for (int i = 0; i < HI; ++i)
+            hreg[i] = buf_load16(xr, ipix[i] >= 0 ? (unsigned)ipix[i] * ld + cofs + iq[i] : FLAIR_OOB);
+    };
+    auto advance_in = [&]() {
+        ++cb;
+        if (cb * BKE >= a.segC[seg]) {
+            cb = 0;
+            segOff += a.segC[seg];
+            ++seg;
+        }
+    };
+    // weights of `rows` output channels starting at co0, K chunk at element offset kofs of a [Cout][9][cin] pack
+    auto issue_w = [&](const __amdgpu_buffer_rsrc_t& wrs, int co0, int coutTot, int cin, int kofs) {
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            const int id = i * NT + tid;
+            const int row = id >> 2;
+            const int co = row / 9, tap9 = row % 9;
+            const bool ok = id < W_PIECES && co0 + co < coutTot;
+            wreg[i] = buf_load16(wrs, ok ? (unsigned)(((co0 + co) * 9 + tap9) * cin + kofs + (id & 3) * VEC) * ESZ
+                                         : FLAIR_OOB);
+        }
+    };
+    auto write_w = [&]() {
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            const int id = i * NT + tid;
+            if (id < W_PIECES) *reinterpret_cast<uint4*>(sw + (id >> 2) * PITCH + (id & 3) * 16) = wreg[i];
+        }
+    };
+    auto write_in = [&](char* dst) {
+#pragma unroll
+        for (int i = 0; i < HI; ++i)
+            if (idst[i] >= 0) *reinterpret_cast<uint4*>(dst + idst[i]) = hreg[i];
+    };
+
+    // 9 taps x one K chunk for one work item (32 pixels x 64 couts): B fragments from `pb` (this lane's
+    // pixel of the input region, row width inW pixels), A fragments from weight rows wb0 / wb1
+    auto compute = [&](const char* pb, int inW, const char* wb0, const char* wb1, f32x16 (&acc)[2]) {
+        uint4 fa0[2][2], fa1[2][2], fb[2][2];
+        auto load_tap = [&](int set, int tap9) {
+            const int kh = tap9 / 3, kw = tap9 % 3;
+            fa0[set][0] = *reinterpret_cast<const uint4*>(wb0 + tap9 * PITCH + 16 * MmaC<E>::chunk(0, lh));
+            fa0[set][1] = *reinterpret_cast<const uint4*>(wb0 + tap9 * PITCH + 16 * MmaC<E>::chunk(1, lh));
+            fa1[set][0] = *reinterpret_cast<const uint4*>(wb1 + tap9 * PITCH + 16 * MmaC<E>::chunk(0, lh));
+            fa1[set][1] = *reinterpret_cast<const uint4*>(wb1 + tap9 * PITCH + 16 * MmaC<E>::chunk(1, lh));
+            const char* hp = pb + (kh * inW + kw) * PITCH;
+            fb[set][0] = *reinterpret_cast<const uint4*>(hp + 16 * MmaC<E>::chunk(0, lh));
+            fb[set][1] = *reinterpret_cast<const uint4*>(hp + 16 * MmaC<E>::chunk(1, lh));
+        };
+        load_tap(0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+        for (int tap9 = 0; tap9 < 9; ++tap9) {
+            const int set = tap9 & 1;
+            if (tap9 < 8) load_tap(set ^ 1, tap9 + 1);
+            MmaC<E>::run(fa0[set], fb[set], acc[0]);
+            MmaC<E>::run(fa1[set], fb[set], acc[1]);
+            if (tap9 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x8, 2 * MmaC<E>::MFMA_PER_STEP, 0);
+        }
+    };
+
+    const __amdgpu_buffer_rsrc_t wBrs = make_rsrc(a.wB, a.wBBytes);
+    const int nBatch = (a.CoutB + WROWS - 1) / WROWS;
+
+    if constexpr (HASA) {
+        // ================================ stage A ================================
+        const __amdgpu_buffer_rsrc_t wArs = make_rsrc(a.wA, a.wABytes);
+        const int nkA = a.CinA / BKE;
+        issue_in();
+        issue_w(wArs, 0, C, a.CinA, segOff + cb * BKE);
+        advance_in();
+        // this lane's pixel of the intermediate region for each of its items; the accumulators start at the
+        // bias (lane layout of the 32x32 MFMA result: register r <-> cout 8*(r/4) + 4*lh + r%4 of the fragment)
+        f32x16 accA[MAXIA][2];
+        int pbOff[MAXIA], wbOff[MAXIA];
+#pragma unroll
+        for (int ii = 0; ii < MAXIA; ++ii) {
+            const int it = wave + ii * NW;
+            const int g = it % NGA, blk = (it / NGA) % NB;
+            int q = g * 32 + lr;
+            if (q >= NPM) q = NPM - 1;                            // tail lanes recompute the last pixel (not stored)
+            pbOff[ii] = ((q / WM) * WA + (q % WM)) * PITCH;
+            wbOff[ii] = ((blk * 64 + lr) * 9) * PITCH;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (a.biasA) bq = *reinterpret_cast<const float4*>(a.biasA + blk * 64 + i * 32 + 8 * gq + 4 * lh);
+                    accA[ii][i][4 * gq] = bq.x; accA[ii][i][4 * gq + 1] = bq.y;
+                    accA[ii][i][4 * gq + 2] = bq.z; accA[ii][i][4 * gq + 3] = bq.w;
+                }
+        }
+        write_in(sin);
+        write_w();
+        __syncthreads();
+        STAMP(1);
+        for (int k = 0; k < nkA; ++k) {
+            if (k + 1 < nkA) {
+                issue_in();
+                issue_w(wArs, 0, C, a.CinA, segOff + cb * BKE);
+                advance_in();
+            } else {
+                issue_w(wBrs, 0, a.CoutB, C, 0);                  // first weights of stage B
+            }
+#pragma unroll
+            for (int ii = 0; ii < MAXIA; ++ii)
+                if (wave + ii * NW < NITA)
+                    compute(sin + pbOff[ii], WA, sw + wbOff[ii], sw + wbOff[ii] + 32 * 9 * PITCH, accA[ii]);
+            __syncthreads();                                       // everyone is done with the staged chunk
+            if (k + 1 < nkA) write_in(sin);
+            write_w();
+            if (k + 1 < nkA) __syncthreads();
+        }
+        STAMP(2);
+        // ---- intermediate -> LDS (bias, activation, zero outside the image, element type rounding)
+#pragma unroll
+        for (int ii = 0; ii < MAXIA; ++ii) {
+            const int it = wave + ii * NW;
+            if (it >= NITA) continue;
+            const int g = it % NGA, blk = (it / NGA) % NB;
+            const int q = g * 32 + lr;
+            if (q >= NPM) continue;
+            const int hh = h0 - 1 + q / WM, ww = w0 - 1 + q % WM;
+            const bool inimg = (unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int co = blk * 64 + i * 32 + 8 * gq + 4 * lh;
+                    float v[4] = {accA[ii][i][4 * gq], accA[ii][i][4 * gq + 1], accA[ii][i][4 * gq + 2],
+                                  accA[ii][i][4 * gq + 3]};
+                    act_vec<4>(v, a.actA);
+                    char* dst = smid + ((co / BKE) * NPM + q) * PITCH + (co % BKE) * ESZ;
+                    if constexpr (sizeof(E) == 4) {
+                        *reinterpret_cast<float4*>(dst) = inimg ? make_float4(v[0], v[1], v[2], v[3])
+                                                                : make_float4(0.f, 0.f, 0.f, 0.f);
+                    } else {
+                        uint2 pk;
+                        pk.x = inimg ? pack2bf(v[0], v[1]) : 0u;
+                        pk.y = inimg ? pack2bf(v[2], v[3]) : 0u;
+                        *reinterpret_cast<uint2*>(dst) = pk;
+                    }
+                }
+        }
+        __syncthreads();
+    } else {
+        // the intermediate IS the input: all channel chunks of the (TH+2) x (TW+2) halo, staged once
+        issue_in();
+        issue_w(wBrs, 0, a.CoutB, C, 0);
+        write_in(smid);
+        write_w();
+        __syncthreads();
+    }
+    STAMP(3);
+
+    // ================================ stage B ================================
+    int pbB[MAXIB], wbB[MAXIB];
+#pragma unroll
+    for (int ii = 0; ii < MAXIB; ++ii) {
+        const int it = wave + ii * NW;
+        const int g = it % NGB, blk = it / NGB;
+        const int q = g * 32 + lr;
+        pbB[ii] = ((q / TW) * WM + (q % TW)) * PITCH;
+        wbB[ii] = ((blk * 64 + lr) * 9) * PITCH;
+    }
+    constexpr int FP = 32 * 4 + 16;                                // f32 staging pitch of the epilogue (32 couts)
+    constexpr int PPX = 32 / VEC;                                  // 16-byte output pieces per pixel and 32 couts
+    for (int batch = 0; batch < nBatch; ++batch) {
+        f32x16 acc[MAXIB][2];
+#pragma unroll
+        for (int ii = 0; ii < MAXIB; ++ii) {
+            const int blk = ((wave + ii * NW) / NGB) % NB;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const float4 bq = *reinterpret_cast<const float4*>(sbias + C + batch * WROWS + blk * 64 + i * 32 +
+                                                                       8 * gq + 4 * lh);
+                    acc[ii][i][4 * gq] = bq.x; acc[ii][i][4 * gq + 1] = bq.y;
+                    acc[ii][i][4 * gq + 2] = bq.z; acc[ii][i][4 * gq + 3] = bq.w;
+                }
+        }
+        for (int ch = 0; ch < NCH; ++ch) {
+            // prefetch the next (batch, chunk) weights
+            const bool lastChunk = ch + 1 == NCH;
+            const bool more = !lastChunk || batch + 1 < nBatch;
+            if (more) issue_w(wBrs, lastChunk ? (batch + 1) * WROWS : batch * WROWS, a.CoutB, C, lastChunk ? 0 : (ch + 1) * BKE);
+#pragma unroll
+            for (int ii = 0; ii < MAXIB; ++ii)
+                if (wave + ii * NW < NITB)
+                    compute(smid + ch * NPM * PITCH + pbB[ii], WM, sw + wbB[ii], sw + wbB[ii] + 32 * 9 * PITCH, acc[ii]);
+            __syncthreads();                                       // sw is free
+            if (!lastChunk) {
+                write_w();
+                __syncthreads();
+            }
+        }
+        if (batch == 0) STAMP(4);
+        // ---- epilogue of this batch: per wave, 32 couts at a time through a private f32 tile in sw
+        char* tilebuf = sw + wave * 32 * FP;
+#pragma unroll
+        for (int ii = 0; ii < MAXIB; ++ii) {
+            const int it = wave + ii * NW;
+            const bool active = it < NITB;
+            const int g = it % NGB, blk = it / NGB;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (active) {
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq)
+                        *reinterpret_cast<float4*>(tilebuf + lr * FP + (8 * gq + 4 * lh) * 4) =
+                            make_float4(acc[ii][i][4 * gq], acc[ii][i][4 * gq + 1], acc[ii][i][4 * gq + 2],
+                                        acc[ii][i][4 * gq + 3]);
+                }
+                // the tile is private to this wavefront: LDS operations of one wave complete in order, so only
+                // the compiler has to be kept from reordering the transposed reads above the writes
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (active) {
+                    const int cobase = batch * WROWS + blk * 64 + i * 32;
+#pragma unroll
+                    for (int it2 = 0; it2 < 32 * PPX / 64; ++it2) {
+                        const int id = it2 * 64 + lane;
+                        const int px = id / PPX, pc = id % PPX;
+                        const int co = cobase + pc * VEC;
+                        const int q = g * 32 + px;
+                        const int hh = h0 + q / TW, ww = w0 + q % TW;
+                        if (co < a.CoutB && hh < a.H) {
+                            const long p = frameOff + (long)hh * a.W + ww;
+                            float v[VEC];
+                            const float* src = reinterpret_cast<const float*>(tilebuf + px * FP) + pc * VEC;
+#pragma unroll
+                            for (int e = 0; e < VEC; e += 4) {
+                                const float4 f = *reinterpret_cast<const float4*>(src + e);
+                                v[e] = f.x; v[e + 1] = f.y; v[e + 2] = f.z; v[e + 3] = f.w;
+                            }
+                            act_vec<VEC>(v, a.actB);
+                            if (a.res0) {
+                                float r[VEC];
+                                Vec16<E>::load(reinterpret_cast<const E*>(a.res0) + p * a.res0Ld + co, r);
+#pragma unroll
+                                for (int e = 0; e < VEC; ++e) v[e] += r[e];
+                            }
+                            if (a.res1) {
+                                float r[VEC];
+                                Vec16<E>::load(reinterpret_cast<const E*>(a.res1) + p * a.res1Ld + co, r);
+#pragma unroll
+                                for (int e = 0; e < VEC; ++e) v[e] += r[e];
+                            }
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e) v[e] *= a.outScale;
+                            Vec16<E>::store(reinterpret_cast<E*>(a.y) + p * a.yLd + co, v);
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __syncthreads();                                           // every wave's tile reads are done: sw may be rewritten
+        if (batch == 0) STAMP(5);
+        if (batch + 1 < nBatch) {
+            write_w();
+            __syncthreads();
+        }
+    }
+    STAMP(6);
+}
+
+template <typename E, int C, int TH, int TW, bool HASA>
+int launch_chain(const ChainArgs& a, hipStream_t s) {
+    constexpr int BKE = MmaC<E>::BKE;
+    constexpr size_t lds = (size_t)(C / BKE) * (TH + 2) * (TW + 2) * 80 + (size_t)C * 9 * 80 +
+                           (HASA ? (size_t)(TH + 4) * (TW + 4) * 80 : 0) + (size_t)(C + CHAIN_MAX_COUTB) * 4;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static_assert((size_t)C * 9 * 80 >= 8 * 32 * (32 * 4 + 16), "epilogue tiles must fit the weight buffer");
+    static bool attr = false;
+    if (!attr) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_chain_kernel<E, C, TH, TW, HASA>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        FLAIR_CHECK(e == hipSuccess, "flair_conv_chain: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr = true;
+    }
+    const int grid = a.T * cdiv(a.H, TH) * (a.W / TW);
+    hipLaunchKernelGGL((conv_chain_kernel<E, C, TH, TW, HASA>), dim3(grid), dim3(512), lds, s, a);
+    FLAIR_LAUNCH_CHECK();
+    return FLAIR_OK;
+}
+
+// Tile choice: 8 x 32 pixels (one image row per MFMA pixel group) when that still gives >= 256 workgroups
+// per frame or the clip is long, else 8 x 8 (the 128x128 level with c = 128: 256 workgroups of 64 pixels);
+// f32 halves the tile height so that the f32 intermediate fits the LDS.
+template <typename E, bool HASA>
+int dispatch_chain(const ChainArgs& a, int C, hipStream_t s) {
+    constexpr int TALL = sizeof(E) == 4 ? 4 : 8;
+    const bool wide = a.W % 32 == 0 && (long)a.T * cdiv(a.H, TALL) * (a.W / 32) >= 192;
+    if (C == 64) return wide ? launch_chain<E, 64, TALL, 32, HASA>(a, s) : launch_chain<E, 64, TALL, 8, HASA>(a, s);
+    return launch_chain<E, 128, TALL, 8, HASA>(a, s);
+}
+
+}  // namespace
+
+extern "C" int flair_conv_chain(const flair_chain_params* p, const void* const* x, const void* wA, const float* biasA,
+                                const void* wB, const float* biasB, const void* res0, const void* res1, void* y,
+                                hipStream_t stream) {
+    FLAIR_CHECK(p && x && wB && y, "flair_conv_chain: null argument");
+    FLAIR_CHECK(p->dtype == FLAIR_F32 || p->dtype == FLAIR_BF16, "flair_conv_chain: bad dtype %d", p->dtype);
+    FLAIR_CHECK(p->nseg >= 1 && p->nseg <= 4, "flair_conv_chain: nseg %d not in 1..4", p->nseg);
+    FLAIR_CHECK(p->T > 0 && p->H > 0 && p->W > 0, "flair_conv_chain: empty shape");
+    FLAIR_CHECK(p->C == 64 || p->C == 128, "flair_conv_chain: intermediate width %d unsupported (64 or 128)", p->C);
+    FLAIR_CHECK(p->W % 8 == 0, "flair_conv_chain: W %% 8 must be 0 (got %d x %d)", p->H, p->W);
+    const int esz = p->dtype == FLAIR_BF16 ? 2 : 4, bke = p->dtype == FLAIR_BF16 ? 32 : 16;
+    FLAIR_CHECK(p->CoutB > 0 && p->CoutB % (16 / esz) == 0 && p->CoutB <= CHAIN_MAX_COUTB,
+                "flair_conv_chain: CoutB %d must be a multiple of %d and at most %d", p->CoutB, 16 / esz, CHAIN_MAX_COUTB);
+    ChainArgs a{};
+    int cin = 0;
+    for (int i = 0; i < p->nseg; ++i) {
+        FLAIR_CHECK(x[i], "flair_conv_chain: segment %d is null", i);
+        FLAIR_CHECK(p->seg_c[i] > 0 && p->seg_c[i] % bke == 0, "flair_conv_chain: segment %d has %d channels; must be a "
+                    "multiple of %d", i, p->seg_c[i], bke);
+        FLAIR_CHECK(p->seg_ld[i] >= p->seg_c[i] && (p->seg_ld[i] * esz) % 16 == 0 && ((uintptr_t)x[i]) % 16 == 0,
+                    "flair_conv_chain: segment %d stride/alignment", i);
+        const unsigned long long bytes = (unsigned long long)p->H * p->W * p->seg_ld[i] * esz;
+        FLAIR_CHECK(bytes < 0x40000000ull, "flair_conv_chain: one frame of segment %d spans %llu bytes (limit 1 GiB)", i, bytes);
+        a.x[i] = x[i]; a.segC[i] = p->seg_c[i]; a.segLd[i] = p->seg_ld[i]; a.segBytes[i] = (unsigned)bytes;
+        cin += p->seg_c[i];
+    }
+    a.nseg = p->nseg;
+    const bool hasA = wA != nullptr;
+    FLAIR_CHECK(hasA || (p->nseg == 1 && cin == p->C), "flair_conv_chain: without stage A the single input must have C channels");
+    a.wA = wA; a.biasA = biasA; a.actA = p->actA; a.CinA = cin;
+    a.wABytes = (unsigned)((unsigned long long)p->C * 9 * cin * esz);
+    a.wB = wB; a.biasB = biasB; a.actB = p->actB; a.CoutB = p->CoutB;
+    {
+        const unsigned long long wb = (unsigned long long)p->CoutB * 9 * p->C * esz;
+        FLAIR_CHECK(wb < 0x80000000ull, "flair_conv_chain: stage-B weights span %llu bytes", wb);
+        a.wBBytes = (unsigned)wb;
+    }
+    FLAIR_CHECK(((uintptr_t)wB) % 16 == 0 && (!wA || ((uintptr_t)wA) % 16 == 0), "flair_conv_chain: weight alignment");
+    FLAIR_CHECK(p->y_ld >= p->CoutB && (p->y_ld * esz) % 16 == 0 && ((uintptr_t)y) % 16 == 0,
+                "flair_conv_chain: output stride/alignment");
+    FLAIR_CHECK(!res0 || ((p->res_ld[0] * esz) % 16 == 0 && ((uintptr_t)res0) % 16 == 0), "flair_conv_chain: res0 alignment");
+    FLAIR_CHECK(!res1 || ((p->res_ld[1] * esz) % 16 == 0 && ((uintptr_t)res1) % 16 == 0), "flair_conv_chain: res1 alignment");
+    a.res0 = res0; a.res1 = res1; a.res0Ld = p->res_ld[0]; a.res1Ld = p->res_ld[1];
+    a.outScale = p->out_scale;
+    a.y = y; a.yLd = p->y_ld;
+    a.T = p->T; a.H = p->H; a.W = p->W;
+    a.dbg = nullptr;
+#ifdef FLAIR_CHAIN_STAMPS
+    if (const char* e = getenv("FLAIR_CHAIN_DBG_PTR")) a.dbg = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 16));
+#endif
+    // partial tiles in H are masked (hh < H); tile widths (32 or 8) divide W by the check above
+    if (p->dtype == FLAIR_BF16)
+        return hasA ? dispatch_chain<bf16_t, true>(a, p->C, stream) : dispatch_chain<bf16_t, false>(a, p->C, stream);
+    return hasA ? dispatch_chain<float, true>(a, p->C, stream) : dispatch_chain<float, false>(a, p->C, stream);
+}

@@ -281,10 +281,19 @@ class ResidualBlocksWithInputConv(nn.Module):
                     w2=_pack(rb.conv2.weight, [(c, c)], dtype, device), b2=_dev(rb.conv2.bias, device))
 
 
+# Fused two-convolution launches (flair_conv_chain) replace pairs of dependent per-frame launches where the
+# micro-benchmark says they win (tools/bench_chain.py, profiles/README.md): the residual block of every trunk
+# and conv_offset[2]+[4]; the c -> 27*G offset convolution runs with its input halo resident in LDS at c = 64.
+USE_CHAIN = True
+
+
 def run_trunk(pk, segs, c, *, extra_res=None, out=None, out_scale=1.0):
     """conv3x3+LeakyReLU -> x + conv(relu(conv(x))) [+ extra_res], scaled."""
     k = (1, 3, 3)
     t1 = ops.conv(segs, pk["w0"], pk["b0"], c, k, act=A.ACT_LRELU01)
+    if USE_CHAIN and ops.chain_supported(t1, c):
+        return ops.conv_chain(t1, pk["w1"], pk["b1"], A.ACT_RELU, pk["w2"], pk["b2"], A.ACT_NONE, c, c,
+                              res0=t1, res1=extra_res, out=out, out_scale=out_scale)
     t2 = ops.conv(t1, pk["w1"], pk["b1"], c, k, act=A.ACT_RELU)
     return ops.conv(t2, pk["w2"], pk["b2"], c, k, res0=t1, res1=extra_res, out=out, out_scale=out_scale)
 
@@ -384,9 +393,16 @@ class BasicVSRPP(nn.Module):
                     feat_n2, flow_n2, cond_n2 = zero_c, None, zero_c
                     ops.vsrpp_prep(prop, None, flow_n1, None, cond_n1, None, None, flowpad)
                 o = ops.conv([cond_n1, cur, cond_n2, flowpad], pk_a["w0"], pk_a["b0"], c, k3, act=A.ACT_LRELU01)
-                o = ops.conv(o, pk_a["w2"], pk_a["b2"], c, k3, act=A.ACT_LRELU01)
-                o = ops.conv(o, pk_a["w4"], pk_a["b4"], c, k3, act=A.ACT_LRELU01)
-                raw = ops.conv(o, pk_a["w6"], pk_a["b6"], 27 * G, k3)
+                if USE_CHAIN and ops.chain_supported(o, c):
+                    o = ops.conv_chain(o, pk_a["w2"], pk_a["b2"], A.ACT_LRELU01, pk_a["w4"], pk_a["b4"],
+                                       A.ACT_LRELU01, c, c)
+                else:
+                    o = ops.conv(o, pk_a["w2"], pk_a["b2"], c, k3, act=A.ACT_LRELU01)
+                    o = ops.conv(o, pk_a["w4"], pk_a["b4"], c, k3, act=A.ACT_LRELU01)
+                if USE_CHAIN and c == 64 and ops.chain_supported(o, c) and W % 32 == 0:
+                    raw = ops.conv_chain(o, None, None, A.ACT_NONE, pk_a["w6"], pk_a["b6"], A.ACT_NONE, c, 27 * G)
+                else:
+                    raw = ops.conv(o, pk_a["w6"], pk_a["b6"], 27 * G, k3)
                 aligned = ops.dcn_align(prop, feat_n2, raw, flow_n1, flow_n2, pk_a["wd"], pk_a["bd"], c,
                                         groups=G, max_mag=mag)
             else:

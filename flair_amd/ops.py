@@ -13,7 +13,7 @@ from . import _lib
 from ._lib import (ACT_LRELU01, ACT_NONE, ACT_RELU, ACT_SILU, ConvParams, check, dtype_code, lib,
                    ptr, stream)
 
-__all__ = ["conv", "group_norm", "nchw_to_clip", "clip_to_nchw", "timestep_embedding", "linear",
+__all__ = ["conv", "conv_chain", "group_norm", "nchw_to_clip", "clip_to_nchw", "timestep_embedding", "linear",
            "qkv_attention", "temporal_attention", "flow_warp", "flow_compose", "resize",
            "dcn_align", "dcn_raw_permutation", "scale_pixels", "predict_xstart", "sampler_update",
            "ACT_NONE", "ACT_RELU", "ACT_LRELU01", "ACT_SILU"]
@@ -205,6 +205,63 @@ def pack_conv_weight(w, seg_channels, dtype, cout_pad=None):
     if cout_pad is not None and cout_pad > cout:
         w = torch.cat([w, w.new_zeros(cout_pad - cout, taps, w.shape[2])], dim=0)
     return w.to(dtype).contiguous()
+
+
+# ---------------------------------------------------------------- fused conv chains
+class ChainParams(ctypes.Structure):
+    _fields_ = [("dtype", ctypes.c_int), ("T", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int),
+                ("C", ctypes.c_int), ("CoutB", ctypes.c_int), ("nseg", ctypes.c_int),
+                ("seg_c", ctypes.c_int * 4), ("seg_ld", ctypes.c_int * 4), ("y_ld", ctypes.c_int),
+                ("res_ld", ctypes.c_int * 2), ("actA", ctypes.c_int), ("actB", ctypes.c_int),
+                ("out_scale", ctypes.c_float)]
+
+
+def chain_supported(xs, c_mid):
+    """Geometry the fused chain kernel covers (flair_conv_chain): W a multiple of 8, 64 or 128 mid channels."""
+    x0 = xs[0] if isinstance(xs, (list, tuple)) else xs
+    return c_mid in (64, 128) and x0.shape[2] % 8 == 0
+
+
+def conv_chain(xs, wA, bA, actA, wB, bB, actB, c_mid, coutB, *, res0=None, res1=None, out_scale=1.0, out=None):
+    """Y = (actB(conv3x3(actA(conv3x3(cat(xs), wA) + bA), wB) + bB) + res0 + res1) * out_scale in ONE launch
+    (the c_mid-channel intermediate stays in LDS).  wA=None: no first stage; xs is the c_mid-channel input,
+    staged once and kept resident while coutB output channels are produced (wide-output convolutions)."""
+    if isinstance(xs, torch.Tensor):
+        xs = [xs]
+    x0 = xs[0]
+    T, H, W, _ = x0.shape
+    p = ChainParams()
+    p.dtype = dtype_code(x0)
+    p.T, p.H, p.W = T, H, W
+    p.C, p.CoutB = c_mid, coutB
+    p.nseg = len(xs)
+    arr = (ctypes.c_void_p * 4)()
+    for i, x in enumerate(xs):
+        assert x.dtype == x0.dtype and x.shape[:3] == x0.shape[:3]
+        p.seg_c[i] = x.shape[3]
+        p.seg_ld[i] = _ld(x)
+        arr[i] = x.data_ptr()
+    if out is None:
+        out = torch.empty((T, H, W, coutB), dtype=x0.dtype, device=x0.device)
+    assert tuple(out.shape[:3]) == (T, H, W) and out.shape[3] >= coutB and out.dtype == x0.dtype
+    p.y_ld = _ld(out)
+    p.res_ld[0] = _ld(res0) if res0 is not None else 0
+    p.res_ld[1] = _ld(res1) if res1 is not None else 0
+    p.actA, p.actB = actA, actB
+    p.out_scale = out_scale
+    assert wB.dtype == x0.dtype and wB.is_contiguous() and (wA is None or (wA.dtype == x0.dtype and wA.is_contiguous()))
+    e0 = _prof_begin()
+    check(lib().flair_conv_chain(ctypes.byref(p), arr, ptr(wA), ptr(_f32(bA)), ptr(wB), ptr(_f32(bB)), ptr(res0),
+                                 ptr(res1), ptr(out), stream()), "flair_conv_chain")
+    if e0 is not None:
+        cin = sum(x.shape[3] for x in xs)
+        esz = x0.element_size()
+        px = T * H * W
+        flops = 2.0 * 9 * px * (c_mid * coutB + (cin * c_mid if wA is not None else 0))
+        nbytes = esz * (px * (cin + coutB * (1 + (res0 is not None) + (res1 is not None)))
+                        + 9 * c_mid * coutB + (9 * cin * c_mid if wA is not None else 0))
+        _prof_end(e0, ("chain", 2 if wA is not None else 1, c_mid), x0.dtype, flops, nbytes)
+    return out
 
 
 # --------------------------------------------------------------------- group norm

@@ -100,6 +100,38 @@ int flair_conv_nhwc(const flair_conv_params* p, const void* const* x, const void
 int flair_conv_variant(const flair_conv_params* p);
 
 
+/* ------------------------------------------------- fused chain of two 3x3 convolutions
+ * M = actA(conv3x3(cat(x), WA) + biasA)   (C = 64 or 128 channels, never leaves the LDS)
+ * Y = (actB(conv3x3(M, WB) + biasB) + res0 + res1) * out_scale        (CoutB channels)
+ * per frame, zero "same" padding on both convolutions.  With WA == NULL there is no stage A: the
+ * single input segment (C channels) is staged once per tile and kept resident while CoutB is walked
+ * in blocks of 64 (wide-output convolutions: the c -> 27*G offset convolution).
+ * Replaces pairs of dependent launches of the BasicVSR++ recurrence: conv_offset[2]+[4] and
+ * conv_offset[4]+[6] of SecondOrderDeformableAlignment (unet_new.py:859-867), conv1+conv2 of mmedit's
+ * ResidualBlockNoBN inside ResidualBlocksWithInputConv with its residual adds (unet_new.py:659-668,
+ * :731-739) -- same rounding points as the two launches (the intermediate is rounded to the element type).
+ *   x[i], seg_c, seg_ld : input segments as in flair_conv_nhwc (T frames of H x W, W % 8 == 0)
+ *   wA : [C][9][sum seg_c] or NULL;  wB : [CoutB][9][C];  biases f32 or NULL
+ *   res0 / res1 : [T][H][W][CoutB-slice] or NULL, added after actB;  y : pixel stride y_ld */
+typedef struct {
+    int dtype;
+    int T, H, W;
+    int C;      /* channels of the intermediate (= output channels of stage A) */
+    int CoutB;
+    int nseg;
+    int seg_c[4];
+    int seg_ld[4];
+    int y_ld;
+    int res_ld[2];
+    int actA, actB;
+    float out_scale;
+} flair_chain_params;
+
+int flair_conv_chain(const flair_chain_params* p, const void* const* x, const void* wA, const float* biasA,
+                     const void* wB, const float* biasB, const void* res0, const void* res1, void* y,
+                     hipStream_t stream);
+
+
 /* ------------------------------------------------------- GroupNorm + SiLU (+ FiLM)
  * y = act( GroupNorm(x) * (1 + scale) + shift ), statistics joint over
  * (C/groups) x frames_per_stat x H x W (frames_per_stat = T for the FLAIR video UNet,

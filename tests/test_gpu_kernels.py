@@ -76,6 +76,57 @@ def test_conv(dev, dtype, case):
     assert_close(from_clip(y), ref, dtype, f"conv {case}")
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [
+    # T, H, W, segs (None: no stage A), c_mid, coutB, actA, actB, nres
+    (1, 256, 256, [64], 64, 64, 2, 2, 0),              # conv_offset[2]+[4] at the 256^2 level (8 x 32 tiles)
+    (1, 128, 128, [128], 128, 128, 1, 0, 2),           # ResidualBlockNoBN at the 128^2 level (8 x 8 tiles)
+    (1, 64, 64, [64], 64, 432, 2, 0, 0),               # conv_offset[4]+[6]: wide second stage
+    (1, 128, 128, [128], 128, 432, 2, 0, 0),
+    (1, 256, 256, None, 64, 432, 0, 0, 0),             # resident-input wide convolution alone
+    (1, 128, 128, None, 128, 432, 0, 0, 0),
+    (3, 32, 32, [64, 64, 32], 64, 64, 2, 1, 1),        # several frames, three input segments, small frame (8 x 8 tiles)
+    (2, 20, 40, [64], 64, 64, 3, 2, 2),                # tiles hang over the image bottom; W % 32 != 0
+    (16, 64, 64, [64], 64, 64, 1, 0, 1),               # clip-level (reconstruction trunk), >= 192 wide tiles
+    (1, 250, 256, [64, 64], 64, 64, 2, 0, 1),          # partial last row of tiles at 256 wide
+    (1, 24, 16, None, 64, 72, 0, 2, 1),                # CoutB not a multiple of 64
+])
+def test_conv_chain(dev, dtype, case):
+    """Two fused 3x3 convolutions (flair_conv_chain) against two plain torch convolutions, the intermediate
+    rounded to the element type exactly where the two-launch path rounds it."""
+    ops = _ops()
+    T, H, W, segs, cm, coutB, actA, actB, nres = case
+    g = torch.Generator().manual_seed(T * 977 + H * 13 + coutB)
+    acts = {0: lambda v: v, 1: F.relu, 2: lambda v: F.leaky_relu(v, 0.1), 3: F.silu}
+    cin = sum(segs) if segs else cm
+    x = rb(torch.randn(T, cin, H, W, generator=g), dtype)
+    wB = rb(torch.randn(coutB, cm, 3, 3, generator=g) / math.sqrt(9 * cm), dtype)
+    bB = torch.randn(coutB, generator=g) * 0.1
+    res = [rb(torch.randn(T, coutB, H, W, generator=g), dtype) for _ in range(nres)]
+    if segs:
+        wA = rb(torch.randn(cm, cin, 3, 3, generator=g) / math.sqrt(9 * cin), dtype)
+        bA = torch.randn(cm, generator=g) * 0.1
+        mid = rb(acts[actA](F.conv2d(x, wA, bA, padding=1)), dtype)
+    else:
+        wA = bA = None
+        mid = x
+    ref = acts[actB](F.conv2d(mid, wB, bB, padding=1))
+    for r in res:
+        ref = ref + r
+    ref = ref * 0.5
+    xs, o = [], 0
+    for c in (segs or [cm]):
+        xs.append(to_clip(x[:, o:o + c], dtype, dev))
+        o += c
+    wAp = ops.pack_conv_weight(wA[:, :, None], [(c, c) for c in segs], dtype).to(dev) if segs else None
+    wBp = ops.pack_conv_weight(wB[:, :, None], [(cm, cm)], dtype).to(dev)
+    rs = [to_clip(r, dtype, dev) for r in res] + [None, None]
+    y = ops.conv_chain(xs, wAp, bA.to(dev) if segs else None, actA, wBp, bB.to(dev), actB, cm, coutB,
+                       res0=rs[0], res1=rs[1], out_scale=0.5)
+    torch.cuda.synchronize()
+    assert_close(from_clip(y), ref, dtype, f"conv_chain {case}")
+
+
 def test_conv_cases_cover_every_kernel_variant():
     """The geometries above dispatch to all 8 conv kernel variants (flair_conv_variant)."""
     ops = _ops()
