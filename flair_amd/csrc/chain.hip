@@ -37,6 +37,7 @@ struct ChainArgs {
     const void* wB; const float* biasB; int actB; int CoutB; unsigned wBBytes;
     const void* res0; const void* res1; int res0Ld, res1Ld;
     float outScale;
+    float actParam; int actPeriod;   // FLAIR_ACT_DCN_OFFSETS on stage B
     void* y; int yLd;
     int T, H, W;
     unsigned long long* dbg;   // probe build only (-DFLAIR_CHAIN_STAMPS): per-workgroup s_memtime stamps
@@ -401,7 +402,10 @@ __global__ __launch_bounds__(512, 2) void conv_chain_kernel(ChainArgs a) {
                                 const float4 f = *reinterpret_cast<const float4*>(src + e);
                                 v[e] = f.x; v[e + 1] = f.y; v[e + 2] = f.z; v[e + 3] = f.w;
                             }
-                            act_vec<VEC>(v, a.actB);
+                            if (a.actB == FLAIR_ACT_DCN_OFFSETS)
+                                dcn_offset_act<VEC>(v, co, a.actParam, a.actPeriod);
+                            else
+                                act_vec<VEC>(v, a.actB);
                             if (a.res0) {
                                 float r[VEC];
                                 Vec16<E>::load(reinterpret_cast<const E*>(a.res0) + p * a.res0Ld + co, r);
@@ -510,6 +514,10 @@ extern "C" int flair_conv_chain(const flair_chain_params* p, const void* const* 
     FLAIR_CHECK(!res1 || ((p->res_ld[1] * esz) % 16 == 0 && ((uintptr_t)res1) % 16 == 0), "flair_conv_chain: res1 alignment");
     a.res0 = res0; a.res1 = res1; a.res0Ld = p->res_ld[0]; a.res1Ld = p->res_ld[1];
     a.outScale = p->out_scale;
+    a.actParam = p->act_param; a.actPeriod = p->act_period;
+    FLAIR_CHECK(p->actA != FLAIR_ACT_DCN_OFFSETS && (p->actB != FLAIR_ACT_DCN_OFFSETS ||
+                                                       (p->act_period > 0 && p->act_period % 24 == 0)),
+                "flair_conv_chain: FLAIR_ACT_DCN_OFFSETS is a stage-B activation with act_period = 3 * deform_groups");
     a.y = y; a.yLd = p->y_ld;
     a.T = p->T; a.H = p->H; a.W = p->W;
     a.dbg = nullptr;

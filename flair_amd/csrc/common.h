@@ -98,6 +98,18 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     }
 }
 
+// FLAIR_ACT_DCN_OFFSETS on VEC consecutive channels starting at co (VEC divides 8, period is a multiple of 24, so
+// all of them fall in the same class): residues mag * tanh(v) = mag * (1 - 2 / (e^{2v} + 1)), masks 1 / (1 + e^{-v}).
+template <int N>
+__device__ __forceinline__ void dcn_offset_act(float (&v)[N], int co, float mag, int period) {
+    const bool residue = 3 * (co % period) < 2 * period;
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+        const float r = __builtin_amdgcn_rcpf(1.f + __expf(residue ? 2.f * v[e] : -v[e]));
+        v[e] = residue ? mag * (1.f - 2.f * r) : r;
+    }
+}
+
 // ---- buffer loads: out-of-range offsets return 0, which gives zero padding for free and keeps
 // the loads unconditional (a select or branch on a load result makes hipcc wait vmcnt(0) at once).
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;

@@ -53,6 +53,8 @@ struct ConvArgs {
     int fbiasLd;
     int debug;             // phase-timing switches, compiled in only with -DFLAIR_TIMING_SWITCHES (see FLAIR_DBG)
     int stride;            // spatial stride (1 or 2; im2col path only)
+    float actParam;        // FLAIR_ACT_DCN_OFFSETS: max residue magnitude
+    int actPeriod;         // FLAIR_ACT_DCN_OFFSETS: 3 * deform groups
     int Hin, Win;          // input frame size (== H, W when stride == 1); H, W, P describe the OUTPUT
 };
 
@@ -126,8 +128,12 @@ __device__ __forceinline__ void store_quad(const ConvArgs& a, long p, int co, fl
         const float* fb = a.fbias + (p / ((long)a.H * a.W)) * a.fbiasLd + co;
         v[0] += fb[0]; v[1] += fb[1]; v[2] += fb[2]; v[3] += fb[3];
     }
+    if (a.act == FLAIR_ACT_DCN_OFFSETS) {
+        dcn_offset_act<4>(v, co, a.actParam, a.actPeriod);
+    } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], a.act);
+        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], a.act);
+    }
     const E* r0 = reinterpret_cast<const E*>(a.res0);
     const E* r1 = reinterpret_cast<const E*>(a.res1);
     if (r0) {
@@ -400,8 +406,12 @@ void conv3x3_halo_kernel(ConvArgs a) {
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) v[e] += fb[e];
                 }
+                if (a.act == FLAIR_ACT_DCN_OFFSETS) {
+                    dcn_offset_act<VEC>(v, co, a.actParam, a.actPeriod);
+                } else {
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) v[e] = apply_act(v[e], a.act);
+                    for (int e = 0; e < VEC; ++e) v[e] = apply_act(v[e], a.act);
+                }
                 if (a.res0) {
                     float r[VEC];
                     Vec16<E>::load(reinterpret_cast<const E*>(a.res0) + p * a.res0Ld + co, r);
@@ -667,8 +677,12 @@ __global__ __launch_bounds__(256 * TH / RPW / CF, (256 * TH / RPW / CF) / 256) v
 #pragma unroll
             for (int e = 0; e < VEC; ++e) v[e] += fb[e];
         }
+        if (a.act == FLAIR_ACT_DCN_OFFSETS) {
+            dcn_offset_act<VEC>(v, co, a.actParam, a.actPeriod);
+        } else {
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) v[e] = apply_act(v[e], a.act);
+            for (int e = 0; e < VEC; ++e) v[e] = apply_act(v[e], a.act);
+        }
         if (a.res0) {
             float r[VEC];
             Vec16<E>::load(reinterpret_cast<const E*>(a.res0) + p * a.res0Ld + co, r);
@@ -1068,6 +1082,11 @@ extern "C" int flair_conv_nhwc(const flair_conv_params* p, const void* const* x,
     a.y = y;
     a.yLd = p->y_ld;
     a.act = p->act;
+    a.actParam = p->act_param;
+    a.actPeriod = p->act_period;
+    FLAIR_CHECK(p->act != FLAIR_ACT_DCN_OFFSETS || (p->act_period > 0 && p->act_period % 24 == 0),
+                "flair_conv_nhwc: FLAIR_ACT_DCN_OFFSETS needs act_period = 3 * deform_groups (multiple of 24), got %d",
+                p->act_period);
     a.outScale = p->out_scale;
     {
         ConvArgs g{};

@@ -23,6 +23,8 @@
 // XOR-swizzled LDS rows); the activation staging is replaced by a 4-corner NHWC gather of
 // 16-byte channel chunks (one deformable group = 8 or 16 contiguous channels).
 
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -39,6 +41,7 @@ struct DcnArgs {
     void* y; int yLd;
     int F, H, W, Cout, G;
     float maxMag;
+    int activated;       // raw holds finished residues / masks (FLAIR_ACT_DCN_OFFSETS upstream)
     long P;
     unsigned xBytes[2], rawBytes, wBytes;
 };
@@ -72,6 +75,21 @@ __device__ __forceinline__ int tile_off(int row, int chunk) {
     return row * (CPR * 16) + ((chunk ^ s) << 4);
 }
 
+// full-rate signed 24-bit multiply (the compiler turns __mul24 into the quarter-rate v_mul_lo_u32 here)
+__device__ __forceinline__ int mul_i24(int a, int b) {
+    int r;
+    asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// (lo, hi) -> packed bf16 pair, round-to-nearest-even; as inline asm so that the vectoriser cannot regroup the
+// conversions by accumulator pair and re-interleave the halves afterwards (4 extra VALU per 8 channels)
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
 __device__ __forceinline__ float fast_tanh(float x) {
     // 1 - 2/(e^{2x}+1); |err| ~ 1e-7 relative, saturates cleanly for large |x|
     const float e = __expf(2.f * x);
@@ -90,7 +108,11 @@ __device__ __forceinline__ float fast_tanh(float x) {
 // into 4 corner addresses and issues 4 unconditional buffer loads (out-of-range corners read
 // 0) plus its share of the weight tile.  Two register sets alternate, so the loads of step
 // k+1 are in flight while step k is blended, written to LDS and multiplied on the matrix cores.
-template <typename E, int NCF, int NPF, int TPP>
+// ONEFRAME (F == 1 and H*W a multiple of the pixel tile: every per-frame call of the recurrence): the feature
+// buffer resources cover exactly one frame, so rows above / below the image fall outside the resource and read 0
+// by the hardware range check; columns left / right of it get weight 0.  That removes the per-corner address
+// selects of the general path (the kernel is VALU-issue bound: ~75 % VALU-active, profiles/r02b_dcn_pmc_sq.txt).
+template <typename E, int NCF, int NPF, int TPP, bool ACTIVATED, bool ONEFRAME>
 __global__ __launch_bounds__(32 * NPF * TPP, (NCF >= 4 ? 32 * NPF * TPP / 256 : 4)) void dcn_kernel(DcnArgs a) {
     constexpr int NT = 32 * NPF * TPP, NW = NT / 64;
     constexpr int TP = 32 * NPF, TC = 32 * NCF, CPR = TPP;
@@ -126,7 +148,9 @@ __global__ __launch_bounds__(32 * NPF * TPP, (NCF >= 4 ? 32 * NPF * TPP / 256 : 
     if (!pvalid) p = a.P - 1;
     const int pw = (int)(p % a.W);
     const int ph = (int)((p / a.W) % a.H);
-    const int pf = (int)(p / ((long)a.W * a.H));
+    // ONEFRAME: the tile lies in one frame, taken from the block-uniform tile origin so that the per-frame buffer
+    // resources below are provably uniform (a per-thread frame index costs a waterfall loop around every load)
+    const int pf = (int)((ONEFRAME ? p0 : p) / ((long)a.W * a.H));
     float2 fl1 = make_float2(0.f, 0.f), fl2 = make_float2(0.f, 0.f);
     if (a.flow1) fl1 = *reinterpret_cast<const float2*>(a.flow1 + p * 2);
     if (a.flow2) fl2 = *reinterpret_cast<const float2*>(a.flow2 + p * 2);
@@ -158,8 +182,10 @@ __global__ __launch_bounds__(32 * NPF * TPP, (NCF >= 4 ? 32 * NPF * TPP / 256 : 
     const int halfC = a.Cin / 2;
     const int cbPerTap = a.Cin / BKE;       // even: both input halves are multiples of BKE
     const int nk = 9 * cbPerTap;
-    const __amdgpu_buffer_rsrc_t xr0 = make_rsrc(a.x[0], a.xBytes[0]);
-    const __amdgpu_buffer_rsrc_t xr1 = make_rsrc(a.x[1], a.xBytes[1]);
+    // ONEFRAME: xBytes is the size of ONE frame, and the tile's frame is block-uniform (H*W % TP == 0)
+    const size_t fo0 = ONEFRAME ? (size_t)pf * a.H * a.W * a.xLd[0] * ESZ : 0, fo1 = ONEFRAME ? (size_t)pf * a.H * a.W * a.xLd[1] * ESZ : 0;
+    const __amdgpu_buffer_rsrc_t xr0 = make_rsrc(reinterpret_cast<const char*>(a.x[0]) + fo0, a.xBytes[0]);
+    const __amdgpu_buffer_rsrc_t xr1 = make_rsrc(reinterpret_cast<const char*>(a.x[1]) + fo1, a.xBytes[1]);
     const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.w, a.wBytes);
     const unsigned frameBase = (unsigned)pf * a.H * a.W;
 
@@ -169,46 +195,78 @@ __global__ __launch_bounds__(32 * NPF * TPP, (NCF >= 4 ? 32 * NPF * TPP / 256 : 
         float wt[4];
     } rs[2];
 
+    // per-thread part of the weight offsets (fixed over the K loop)
+    unsigned wrow[WR];
+#pragma unroll
+    for (int j = 0; j < WR; ++j) {
+        const int id = tid + j * NT;
+        const int n = id / CPR, ch = id % CPR;
+        wrow[j] = n < a.Cout && n < TC ? (unsigned)(n * 9 * a.Cin + ch * VEC) * ESZ : FLAIR_OOB;
+    }
     int itap = 0, icb = 0, ikh = 0, ikw = 0;   // K-loop position of the NEXT issue (block uniform)
+    const int rawRow = srow * rawPitch;        // this thread's pixel inside a staged raw slab
+    const float fH = (float)a.H, fW = (float)a.W;
     auto issue = [&](Regs& r) {
         const int tap = itap, cb = icb;
         const int c = cb * BKE + q * VEC;
         const int g = c >> cpgShift;
-        const E* myraw = reinterpret_cast<const E*>(sraw + ((tap & 1) * TP + srow) * rawPitch);
+        const E* myraw = reinterpret_cast<const E*>(sraw + (tap & 1) * TP * rawPitch + rawRow);
         const float ry = ET<E>::ld(myraw + 2 * g), rx = ET<E>::ld(myraw + 2 * g + 1);
         const float rm = ET<E>::ld(myraw + 2 * G + g);
         const float2 fl = g < G / 2 ? fl1 : fl2;
-        const float sy = (float)(ph - 1 + ikh) + a.maxMag * fast_tanh(ry) + fl.y;
-        const float sx = (float)(pw - 1 + ikw) + a.maxMag * fast_tanh(rx) + fl.x;
-        const float mk = __builtin_amdgcn_rcpf(1.f + __expf(-rm));
+        // ACTIVATED (compile time): the residues and the mask are used as stored, no transcendental per group
+        float sy = (float)(ph - 1 + ikh) + fl.y, sx = (float)(pw - 1 + ikw) + fl.x, mk;
+        if constexpr (ACTIVATED) {
+            sy += ry;
+            sx += rx;
+            mk = rm;
+        } else {
+            sy += a.maxMag * fast_tanh(ry);
+            sx += a.maxMag * fast_tanh(rx);
+            mk = __builtin_amdgcn_rcpf(1.f + __expf(-rm));
+        }
         const float fy = floorf(sy), fx = floorf(sx);
         const float ay = sy - fy, ax = sx - fx;
-        // clamp before the int conversion so wild offsets cannot overflow
-        const int y0 = (int)fminf(fmaxf(fy, -2.f), (float)a.H), x0 = (int)fminf(fmaxf(fx, -2.f), (float)a.W);
-        r.wt[0] = (1.f - ay) * (1.f - ax) * mk;
-        r.wt[1] = (1.f - ay) * ax * mk;
-        r.wt[2] = ay * (1.f - ax) * mk;
-        r.wt[3] = ay * ax * mk;
+        // clamp before the int conversion so wild offsets cannot overflow (one v_med3 each)
+        const int y0 = (int)__builtin_amdgcn_fmed3f(fy, -2.f, fH), x0 = (int)__builtin_amdgcn_fmed3f(fx, -2.f, fW);
         const bool second = cb * BKE >= halfC;                // block-uniform (halfC % BKE == 0)
         const unsigned ld = (unsigned)(second ? a.xLd[1] : a.xLd[0]) * ESZ;
         const unsigned coff = (unsigned)(c - (second ? halfC : 0)) * ESZ;
         const __amdgpu_buffer_rsrc_t xr = second ? xr1 : xr0;
-        // one multiply for the top-left corner, the other three are adds (v_mul_lo_u32 is quarter rate)
-        const unsigned o00 = (frameBase + (unsigned)(y0 * a.W + x0)) * ld + coff;
         const unsigned rowStep = (unsigned)a.W * ld;
-        const bool yok0 = pvalid && (unsigned)y0 < (unsigned)a.H, yok1 = pvalid && (unsigned)(y0 + 1) < (unsigned)a.H;
-        const bool xok0 = (unsigned)x0 < (unsigned)a.W, xok1 = (unsigned)(x0 + 1) < (unsigned)a.W;
-        r.c[0] = buf_load16(xr, yok0 && xok0 ? o00 : FLAIR_OOB);
-        r.c[1] = buf_load16(xr, yok0 && xok1 ? o00 + ld : FLAIR_OOB);
-        r.c[2] = buf_load16(xr, yok1 && xok0 ? o00 + rowStep : FLAIR_OOB);
-        r.c[3] = buf_load16(xr, yok1 && xok1 ? o00 + rowStep + ld : FLAIR_OOB);
-#pragma unroll
-        for (int j = 0; j < WR; ++j) {
-            const int id = tid + j * NT;
-            const int n = id / CPR, ch = id % CPR;
-            r.w[j] = buf_load16(wrs, n < a.Cout && n < TC ? (unsigned)((n * 9 + tap) * a.Cin + cb * BKE + ch * VEC) * ESZ
-                                                          : FLAIR_OOB);
+        // one multiply for the top-left corner, the other three are adds; SIGNED 24-bit multiplies are full rate
+        // (v_mul_lo_u32 is quarter rate) and keep the arithmetic consistent mod 2^32 when the top-left corner is
+        // outside the image while a neighbour is inside: |pixel index| < 2^23 and byte strides < 2^23 (host check)
+        if constexpr (ONEFRAME) {
+            const float wx0 = (unsigned)x0 < (unsigned)a.W ? (1.f - ax) * mk : 0.f;
+            const float wx1 = (unsigned)(x0 + 1) < (unsigned)a.W ? ax * mk : 0.f;
+            r.wt[0] = (1.f - ay) * wx0;
+            r.wt[1] = (1.f - ay) * wx1;
+            r.wt[2] = ay * wx0;
+            r.wt[3] = ay * wx1;
+            const unsigned o00 =
+                (unsigned)mul_i24(mul_i24(y0, a.W) + x0, (int)ld) + coff;
+            r.c[0] = buf_load16(xr, o00);
+            r.c[1] = buf_load16(xr, o00 + ld);
+            r.c[2] = buf_load16(xr, o00 + rowStep);
+            r.c[3] = buf_load16(xr, o00 + rowStep + ld);
+        } else {
+            r.wt[0] = (1.f - ay) * (1.f - ax) * mk;
+            r.wt[1] = (1.f - ay) * ax * mk;
+            r.wt[2] = ay * (1.f - ax) * mk;
+            r.wt[3] = ay * ax * mk;
+            const unsigned o00 = (unsigned)mul_i24(
+                                     (int)frameBase + mul_i24(y0, a.W) + x0, (int)ld) + coff;
+            const bool yok0 = pvalid && (unsigned)y0 < (unsigned)a.H, yok1 = pvalid && (unsigned)(y0 + 1) < (unsigned)a.H;
+            const bool xok0 = (unsigned)x0 < (unsigned)a.W, xok1 = (unsigned)(x0 + 1) < (unsigned)a.W;
+            r.c[0] = buf_load16(xr, yok0 && xok0 ? o00 : FLAIR_OOB);
+            r.c[1] = buf_load16(xr, yok0 && xok1 ? o00 + ld : FLAIR_OOB);
+            r.c[2] = buf_load16(xr, yok1 && xok0 ? o00 + rowStep : FLAIR_OOB);
+            r.c[3] = buf_load16(xr, yok1 && xok1 ? o00 + rowStep + ld : FLAIR_OOB);
         }
+        const unsigned wk = (unsigned)(tap * a.Cin + cb * BKE) * ESZ;      // block-uniform part of the weight offset
+#pragma unroll
+        for (int j = 0; j < WR; ++j) r.w[j] = buf_load16(wrs, wrow[j] == FLAIR_OOB ? FLAIR_OOB : wrow[j] + wk);
         if (++icb == cbPerTap) {
             icb = 0;
             ++itap;
@@ -219,20 +277,44 @@ __global__ __launch_bounds__(32 * NPF * TPP, (NCF >= 4 ? 32 * NPF * TPP / 256 : 
         }
     };
     auto blend_and_stage = [&](const Regs& r, int buf) {
-        float acc[VEC];
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float v[VEC];
-            Vec16<E>::load(reinterpret_cast<const E*>(&r.c[i]), v);
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) acc[e] = fmaf(r.wt[i], v[e], acc[e]);
-        }
         char* base = stile + buf * BUF;
-        alignas(16) E out[VEC];
-        Vec16<E>::store(out, acc);
-        *reinterpret_cast<uint4*>(base + TC * CPR * 16 + tile_off<CPR>(srow, q)) = *reinterpret_cast<const uint4*>(out);
+        uint4 outv;
+        if constexpr (sizeof(E) == 2) {
+            // even / odd channels of each bf16 pair accumulate separately, so the result packs with one
+            // v_cvt_pk_bf16_f32 per dword (no re-interleaving)
+            // (two-wide vectors: v_pk_fma_f32, one instruction per two channels)
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2 lo[2] = {{0.f, 0.f}, {0.f, 0.f}}, hi[2] = {{0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned d[4] = {r.c[i].x, r.c[i].y, r.c[i].z, r.c[i].w};
+                const f32x2 w = {r.wt[i], r.wt[i]};
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const f32x2 vl = {__uint_as_float(d[2 * j] << 16), __uint_as_float(d[2 * j + 1] << 16)};
+                    const f32x2 vh = {__uint_as_float(d[2 * j] & 0xffff0000u), __uint_as_float(d[2 * j + 1] & 0xffff0000u)};
+                    lo[j] = __builtin_elementwise_fma(w, vl, lo[j]);
+                    hi[j] = __builtin_elementwise_fma(w, vh, hi[j]);
+                }
+            }
+            outv = make_uint4(cvt_pk_bf16(lo[0].x, hi[0].x), cvt_pk_bf16(lo[0].y, hi[0].y), cvt_pk_bf16(lo[1].x, hi[1].x),
+                              cvt_pk_bf16(lo[1].y, hi[1].y));
+        } else {
+            float acc[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v[VEC];
+                Vec16<E>::load(reinterpret_cast<const E*>(&r.c[i]), v);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[e] = fmaf(r.wt[i], v[e], acc[e]);
+            }
+            alignas(16) E out[VEC];
+            Vec16<E>::store(out, acc);
+            outv = *reinterpret_cast<const uint4*>(out);
+        }
+        *reinterpret_cast<uint4*>(base + TC * CPR * 16 + tile_off<CPR>(srow, q)) = outv;
 #pragma unroll
         for (int j = 0; j < WR; ++j) {
             const int id = tid + j * NT;
@@ -343,21 +425,36 @@ __global__ __launch_bounds__(32 * NPF * TPP, (NCF >= 4 ? 32 * NPF * TPP / 256 : 
 
 }  // namespace
 
-template <typename E, int NCF, int NPF, int TPP>
-static int launch_dcn(const DcnArgs& a, hipStream_t stream) {
+template <typename E, int NCF, int NPF, int TPP, bool ACTIVATED, bool ONEFRAME>
+static int launch_dcn_v(const DcnArgs& a0, hipStream_t stream) {
+    DcnArgs a = a0;
+    if (ONEFRAME) {      // resources cover one frame: rows outside the image fall outside the resource
+        const unsigned long long half = a.Cin / 2, hw = (unsigned long long)a.H * a.W;
+        a.xBytes[0] = (unsigned)(((hw - 1) * a.xLd[0] + half) * sizeof(E));
+        a.xBytes[1] = (unsigned)(((hw - 1) * a.xLd[1] + half) * sizeof(E));
+    }
     constexpr int NT = 32 * NPF * TPP, TP = 32 * NPF, TC = 32 * NCF;
     const int rawPitch = 3 * a.G * (int)sizeof(E) + 16;
     const size_t lds = (size_t)2 * TP * rawPitch + 2 * (TC + TP) * TPP * 16;
     static bool attr = false;
     if (!attr) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_kernel<E, NCF, NPF, TPP>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_kernel<E, NCF, NPF, TPP, ACTIVATED, ONEFRAME>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         FLAIR_CHECK(e == hipSuccess, "flair_dcn_align: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr = true;
     }
-    hipLaunchKernelGGL((dcn_kernel<E, NCF, NPF, TPP>), dim3(cdiv(a.P, TP)), dim3(NT), lds, stream, a);
+    hipLaunchKernelGGL((dcn_kernel<E, NCF, NPF, TPP, ACTIVATED, ONEFRAME>), dim3(cdiv(a.P, TP)), dim3(NT), lds, stream, a);
     FLAIR_LAUNCH_CHECK();
     return FLAIR_OK;
+}
+
+template <typename E, int NCF, int NPF, int TPP>
+static int launch_dcn(const DcnArgs& a, hipStream_t stream) {
+    // the recurrence calls per frame with activated offsets; everything else takes the general kernel
+    const bool oneframe = ((long)a.H * a.W) % (32 * NPF) == 0;
+    if (a.activated && oneframe) return launch_dcn_v<E, NCF, NPF, TPP, true, true>(a, stream);
+    if (a.activated) return launch_dcn_v<E, NCF, NPF, TPP, true, false>(a, stream);
+    return launch_dcn_v<E, NCF, NPF, TPP, false, false>(a, stream);
 }
 
 extern "C" int flair_dcn_align(const flair_dcn_params* p, const void* x0, const void* x1, const void* raw,
@@ -379,18 +476,26 @@ extern "C" int flair_dcn_align(const flair_dcn_params* p, const void* x0, const 
     a.Cin = p->Cin; a.raw = raw; a.rawLd = p->raw_ld; a.flow1 = flow1; a.flow2 = flow2;
     a.w = w; a.bias = bias; a.y = y; a.yLd = p->y_ld;
     a.F = p->F; a.H = p->H; a.W = p->W; a.Cout = p->Cout; a.G = p->G; a.maxMag = p->max_residue_magnitude;
+    a.activated = p->raw_activated;
     a.P = (long)p->F * p->H * p->W;
     const unsigned long long half = p->Cin / 2;
     const unsigned long long b0 = ((unsigned long long)(a.P - 1) * p->x_ld[0] + half) * esz;
     const unsigned long long b1 = ((unsigned long long)(a.P - 1) * p->x_ld[1] + half) * esz;
     const unsigned long long br = ((unsigned long long)(a.P - 1) * p->raw_ld + 27 * p->G) * esz;
     FLAIR_CHECK(b0 < 0x80000000ull && b1 < 0x80000000ull && br < 0x80000000ull, "flair_dcn_align: tensor spans >= 2 GiB");
+    FLAIR_CHECK(a.P + 2l * p->W + 2 < (1l << 23) && (long)p->x_ld[0] * esz < (1l << 23) && (long)p->x_ld[1] * esz < (1l << 23),
+                "flair_dcn_align: F*H*W = %ld pixels (limit 2^23 per call: call per frame)", a.P);
     a.xBytes[0] = (unsigned)b0; a.xBytes[1] = (unsigned)b1; a.rawBytes = (unsigned)((br + 15) / 16 * 16);
     a.wBytes = (unsigned)((unsigned long long)p->Cout * 9 * p->Cin * esz);
     // Tile choice (measured on per-frame 256^2 / 128^2 calls, profiles/README.md).  c=64: 64 pixels x 64
     // couts with 8 threads per pixel, so one gather instruction fetches the whole 128-byte channel row of a
     // corner (two waves share each MFMA pair, K split); c=128: 32 pixels x 128 couts, 8 threads per pixel.
-    if (p->dtype == FLAIR_BF16)
-        return p->Cout <= 64 ? launch_dcn<bf16_t, 2, 2, 8>(a, stream) : launch_dcn<bf16_t, 4, 1, 8>(a, stream);
+    if (p->dtype == FLAIR_BF16) {
+        if (p->Cout > 64) return launch_dcn<bf16_t, 4, 1, 8>(a, stream);
+        // 64-pixel tiles need 47 KB of LDS: 3 workgroups per CU, so a 256x256 frame (1024 tiles) runs as 768 + 256
+        // (a second, one-third-full round).  128-pixel tiles (78 KB, 2 per CU, 16 wavefronts each) make it one full round.
+        static const int wide = getenv("FLAIR_DCN_TILE") ? atoi(getenv("FLAIR_DCN_TILE")) : 128;
+        return (wide >= 128 && a.P >= 128 * 512) ? launch_dcn<bf16_t, 2, 4, 8>(a, stream) : launch_dcn<bf16_t, 2, 2, 8>(a, stream);
+    }
     return p->Cout <= 64 ? launch_dcn<float, 2, 2, 4>(a, stream) : launch_dcn<float, 4, 1, 8>(a, stream);
 }

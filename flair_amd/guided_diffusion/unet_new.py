@@ -282,16 +282,21 @@ class ResidualBlocksWithInputConv(nn.Module):
 
 
 # Fused two-convolution launches (flair_conv_chain) replace pairs of dependent per-frame launches where the
-# micro-benchmark says they win (tools/bench_chain.py, profiles/README.md): the residual block of every trunk
-# and conv_offset[2]+[4]; the c -> 27*G offset convolution runs with its input halo resident in LDS at c = 64.
-USE_CHAIN = True
+# in-situ kernel trace says they win (profiles/README.md, r02h): at c = 64 (256x256 frames: 24.9 -> 19.0 us per
+# pair) the residual block of every trunk and conv_offset[2]+[4], and the c -> 27*G offset convolution with its
+# input halo resident in LDS.  At c = 128 (128x128 frames: 64-pixel tiles, every workgroup streams all weights)
+# the fused pair measured 24.1 us against 22.5 us for the two launches, so that level keeps the two launches.
+import os as _os
+
+USE_CHAIN = _os.environ.get("FLAIR_CHAIN", "1") != "0"          # A/B switches for same-box comparisons
+ACT_IN_OFFSET_CONV = _os.environ.get("FLAIR_DCN_ACT", "1") != "0"
 
 
 def run_trunk(pk, segs, c, *, extra_res=None, out=None, out_scale=1.0):
     """conv3x3+LeakyReLU -> x + conv(relu(conv(x))) [+ extra_res], scaled."""
     k = (1, 3, 3)
     t1 = ops.conv(segs, pk["w0"], pk["b0"], c, k, act=A.ACT_LRELU01)
-    if USE_CHAIN and ops.chain_supported(t1, c):
+    if USE_CHAIN and c == 64 and ops.chain_supported(t1, c):
         return ops.conv_chain(t1, pk["w1"], pk["b1"], A.ACT_RELU, pk["w2"], pk["b2"], A.ACT_NONE, c, c,
                               res0=t1, res1=extra_res, out=out, out_scale=out_scale)
     t2 = ops.conv(t1, pk["w1"], pk["b1"], c, k, act=A.ACT_RELU)
@@ -393,18 +398,22 @@ class BasicVSRPP(nn.Module):
                     feat_n2, flow_n2, cond_n2 = zero_c, None, zero_c
                     ops.vsrpp_prep(prop, None, flow_n1, None, cond_n1, None, None, flowpad)
                 o = ops.conv([cond_n1, cur, cond_n2, flowpad], pk_a["w0"], pk_a["b0"], c, k3, act=A.ACT_LRELU01)
-                if USE_CHAIN and ops.chain_supported(o, c):
+                if USE_CHAIN and c == 64 and ops.chain_supported(o, c):
                     o = ops.conv_chain(o, pk_a["w2"], pk_a["b2"], A.ACT_LRELU01, pk_a["w4"], pk_a["b4"],
                                        A.ACT_LRELU01, c, c)
                 else:
                     o = ops.conv(o, pk_a["w2"], pk_a["b2"], c, k3, act=A.ACT_LRELU01)
                     o = ops.conv(o, pk_a["w4"], pk_a["b4"], c, k3, act=A.ACT_LRELU01)
+                # the offset convolution applies 10*tanh / sigmoid in its epilogue (once per value, where the VALU
+                # is idle) instead of the alignment kernel re-deriving them per gathered group (it is VALU-bound)
+                act6 = A.ACT_DCN_OFFSETS if ACT_IN_OFFSET_CONV else A.ACT_NONE
                 if USE_CHAIN and c == 64 and ops.chain_supported(o, c) and W % 32 == 0:
-                    raw = ops.conv_chain(o, None, None, A.ACT_NONE, pk_a["w6"], pk_a["b6"], A.ACT_NONE, c, 27 * G)
+                    raw = ops.conv_chain(o, None, None, A.ACT_NONE, pk_a["w6"], pk_a["b6"], act6, c, 27 * G,
+                                         act_param=mag, act_period=3 * G)
                 else:
-                    raw = ops.conv(o, pk_a["w6"], pk_a["b6"], 27 * G, k3)
+                    raw = ops.conv(o, pk_a["w6"], pk_a["b6"], 27 * G, k3, act=act6, act_param=mag, act_period=3 * G)
                 aligned = ops.dcn_align(prop, feat_n2, raw, flow_n1, flow_n2, pk_a["wd"], pk_a["bd"], c,
-                                        groups=G, max_mag=mag)
+                                        groups=G, max_mag=mag, raw_activated=ACT_IN_OFFSET_CONV)
             else:
                 aligned = zero_c
             segs = [cur] + [o_[idx:idx + 1] for o_ in others] + [aligned]

@@ -10,13 +10,13 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import (ACT_LRELU01, ACT_NONE, ACT_RELU, ACT_SILU, ConvParams, check, dtype_code, lib,
+from ._lib import (ACT_DCN_OFFSETS, ACT_LRELU01, ACT_NONE, ACT_RELU, ACT_SILU, ConvParams, check, dtype_code, lib,
                    ptr, stream)
 
 __all__ = ["conv", "conv_chain", "group_norm", "nchw_to_clip", "clip_to_nchw", "timestep_embedding", "linear",
            "qkv_attention", "temporal_attention", "flow_warp", "flow_compose", "resize",
            "dcn_align", "dcn_raw_permutation", "scale_pixels", "predict_xstart", "sampler_update",
-           "ACT_NONE", "ACT_RELU", "ACT_LRELU01", "ACT_SILU"]
+           "ACT_NONE", "ACT_RELU", "ACT_LRELU01", "ACT_SILU", "ACT_DCN_OFFSETS"]
 
 
 class GnParams(ctypes.Structure):
@@ -58,7 +58,7 @@ class DcnParams(ctypes.Structure):
     _fields_ = [("dtype", ctypes.c_int), ("F", ctypes.c_int), ("H", ctypes.c_int),
                 ("W", ctypes.c_int), ("Cin", ctypes.c_int), ("Cout", ctypes.c_int),
                 ("G", ctypes.c_int), ("x_ld", ctypes.c_int * 2), ("raw_ld", ctypes.c_int),
-                ("y_ld", ctypes.c_int), ("max_residue_magnitude", ctypes.c_float)]
+                ("y_ld", ctypes.c_int), ("max_residue_magnitude", ctypes.c_float), ("raw_activated", ctypes.c_int)]
 
 
 def _ld(t):
@@ -87,7 +87,7 @@ def pad_channels(c, dtype):
 
 # --------------------------------------------------------------------------- conv
 def conv(xs, weight, bias, cout, kernel, *, out=None, act=ACT_NONE, res0=None, res1=None,
-         out_scale=1.0, stride=1, frame_bias=None):
+         out_scale=1.0, stride=1, frame_bias=None, act_param=0.0, act_period=0):
     """Y = act(conv(cat(xs), W) + bias) + res0 + res1, times out_scale.
 
     xs: one clip tensor or a list of up to 4 (channel-concatenated implicitly; each
@@ -122,6 +122,7 @@ def conv(xs, weight, bias, cout, kernel, *, out=None, act=ACT_NONE, res0=None, r
     p.res_ld[0] = _ld(res0) if res0 is not None else 0
     p.res_ld[1] = _ld(res1) if res1 is not None else 0
     p.act = act
+    p.act_param, p.act_period = act_param, act_period
     p.out_scale = out_scale
     assert weight.dtype == x0.dtype and weight.is_contiguous()
     e0 = _prof_begin()
@@ -213,16 +214,22 @@ class ChainParams(ctypes.Structure):
                 ("C", ctypes.c_int), ("CoutB", ctypes.c_int), ("nseg", ctypes.c_int),
                 ("seg_c", ctypes.c_int * 4), ("seg_ld", ctypes.c_int * 4), ("y_ld", ctypes.c_int),
                 ("res_ld", ctypes.c_int * 2), ("actA", ctypes.c_int), ("actB", ctypes.c_int),
-                ("out_scale", ctypes.c_float)]
+                ("out_scale", ctypes.c_float), ("act_param", ctypes.c_float), ("act_period", ctypes.c_int)]
 
 
 def chain_supported(xs, c_mid):
-    """Geometry the fused chain kernel covers (flair_conv_chain): W a multiple of 8, 64 or 128 mid channels."""
+    """Where the fused chain kernel is used: the geometry flair_conv_chain covers (W a multiple of 8, 64 or 128
+    mid channels) AND a launch of at most ~2 workgroups per CU (per-frame calls of the recurrence).  Clip-level
+    calls (thousands of tiles) stay on the two-launch path: there independent workgroups, two per CU, already
+    overlap each other's fetch / MFMA / store phases, which one 135 KB workgroup per CU cannot."""
     x0 = xs[0] if isinstance(xs, (list, tuple)) else xs
-    return c_mid in (64, 128) and x0.shape[2] % 8 == 0
+    T, H, W, _ = x0.shape
+    tiles = T * ((H + 7) // 8) * (W // 32 if W % 32 == 0 and T * ((H + 7) // 8) * (W // 32) >= 192 else W // 8)
+    return c_mid in (64, 128) and W % 8 == 0 and tiles <= 512
 
 
-def conv_chain(xs, wA, bA, actA, wB, bB, actB, c_mid, coutB, *, res0=None, res1=None, out_scale=1.0, out=None):
+def conv_chain(xs, wA, bA, actA, wB, bB, actB, c_mid, coutB, *, res0=None, res1=None, out_scale=1.0, out=None,
+               act_param=0.0, act_period=0):
     """Y = (actB(conv3x3(actA(conv3x3(cat(xs), wA) + bA), wB) + bB) + res0 + res1) * out_scale in ONE launch
     (the c_mid-channel intermediate stays in LDS).  wA=None: no first stage; xs is the c_mid-channel input,
     staged once and kept resident while coutB output channels are produced (wide-output convolutions)."""
@@ -248,6 +255,7 @@ def conv_chain(xs, wA, bA, actA, wB, bB, actB, c_mid, coutB, *, res0=None, res1=
     p.res_ld[0] = _ld(res0) if res0 is not None else 0
     p.res_ld[1] = _ld(res1) if res1 is not None else 0
     p.actA, p.actB = actA, actB
+    p.act_param, p.act_period = act_param, act_period
     p.out_scale = out_scale
     assert wB.dtype == x0.dtype and wB.is_contiguous() and (wA is None or (wA.dtype == x0.dtype and wA.is_contiguous()))
     e0 = _prof_begin()
@@ -460,8 +468,9 @@ def dcn_raw_permutation(groups):
     return perm
 
 
-def dcn_align(x0, x1, raw, flow1, flow2, weight, bias, cout, *, groups=16, max_mag=10.0, out=None):
-    """raw: conv_offset output in TAP-MAJOR channel order (see dcn_raw_permutation)."""
+def dcn_align(x0, x1, raw, flow1, flow2, weight, bias, cout, *, groups=16, max_mag=10.0, out=None, raw_activated=False):
+    """raw: conv_offset output in TAP-MAJOR channel order (see dcn_raw_permutation); raw_activated: the producing
+    convolution already applied ACT_DCN_OFFSETS (max_mag * tanh on the residues, sigmoid on the masks)."""
     F_, H, W, ch = x0.shape
     p = DcnParams()
     p.dtype = dtype_code(x0)
@@ -473,6 +482,7 @@ def dcn_align(x0, x1, raw, flow1, flow2, weight, bias, cout, *, groups=16, max_m
         out = torch.empty((F_, H, W, cout), dtype=x0.dtype, device=x0.device)
     p.y_ld = _ld(out)
     p.max_residue_magnitude = max_mag
+    p.raw_activated = int(raw_activated)
     e0 = _prof_begin()
     check(lib().flair_dcn_align(ctypes.byref(p), ptr(x0), ptr(x1), ptr(raw), ptr(flow1), ptr(flow2), ptr(weight),
                                 ptr(_f32(bias)), ptr(out), stream()), "flair_dcn_align")

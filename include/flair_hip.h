@@ -45,7 +45,13 @@ typedef enum {
     FLAIR_ACT_NONE = 0,
     FLAIR_ACT_RELU = 1,
     FLAIR_ACT_LRELU01 = 2, /* LeakyReLU(0.1) */
-    FLAIR_ACT_SILU = 3
+    FLAIR_ACT_SILU = 3,
+    /* offset / mask activation of SecondOrderDeformableAlignment (unet_new.py:879-885) applied by the
+     * convolution that PRODUCES the 27*G tap-major offset channels: with period = 3*G (act_period),
+     * channel co -> act_param * tanh(v) if co % period < 2*period/3 (the (dy,dx) residues, act_param =
+     * max_residue_magnitude), else sigmoid(v) (the modulation mask).  flair_dcn_align then takes the
+     * finished values (raw_activated = 1) instead of re-deriving them per gathered channel group. */
+    FLAIR_ACT_DCN_OFFSETS = 4
 } flair_act;
 
 /* Last error message of the calling thread ("" if none). */
@@ -87,6 +93,8 @@ typedef struct {
     int frame_bias_ld;
     int stride; /* spatial stride 1 (default when 0) or 2: T,H,W describe the INPUT, the output is
                  * ceil(H/stride) x ceil(W/stride) (PyTorch Conv2d(k, stride, padding=k//2)) */
+    float act_param; /* FLAIR_ACT_DCN_OFFSETS: max_residue_magnitude */
+    int act_period;  /* FLAIR_ACT_DCN_OFFSETS: 3 * deform_groups (multiple of 24) */
 } flair_conv_params;
 
 size_t flair_conv_workspace_bytes(const flair_conv_params* p);
@@ -125,6 +133,8 @@ typedef struct {
     int res_ld[2];
     int actA, actB;
     float out_scale;
+    float act_param; /* actB == FLAIR_ACT_DCN_OFFSETS: max_residue_magnitude */
+    int act_period;  /* actB == FLAIR_ACT_DCN_OFFSETS: 3 * deform_groups */
 } flair_chain_params;
 
 int flair_conv_chain(const flair_chain_params* p, const void* const* x, const void* wA, const float* biasA,
@@ -304,6 +314,8 @@ typedef struct {
     int x_ld[2];
     int raw_ld, y_ld;
     float max_residue_magnitude;
+    int raw_activated; /* 1: raw already holds max_residue_magnitude*tanh / sigmoid values
+                        * (produced with FLAIR_ACT_DCN_OFFSETS); 0: pre-activations */
 } flair_dcn_params;
 int flair_dcn_align(const flair_dcn_params* p, const void* x0, const void* x1, const void* raw,
                     const float* flow1, const float* flow2, const void* w, const float* bias,

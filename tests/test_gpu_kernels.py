@@ -301,6 +301,63 @@ def test_dcn(dev, dtype, c, hw):
     assert_close(from_clip(y), ref, dtype, f"dcn c={c}", scale=2.0)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("c,hw", [(64, (32, 32)), (128, (16, 40))])
+def test_dcn_activated_raw(dev, dtype, c, hw):
+    """flair_dcn_align with raw_activated=1: residues / masks arrive finished (the producing convolution's
+    FLAIR_ACT_DCN_OFFSETS epilogue), rounded to the element type like any stored activation."""
+    from oracle.thirdparty import deform_conv2d
+    ops = _ops()
+    g = torch.Generator().manual_seed(33 + c)
+    H, W, G = hw[0], hw[1], 16
+    x = rb(torch.randn(1, 2 * c, H, W, generator=g), dtype)
+    raw = torch.randn(1, 27 * G, H, W, generator=g)
+    f1 = torch.randn(1, H, W, 2, generator=g) * 2
+    f2 = torch.randn(1, H, W, 2, generator=g) * 2
+    w = rb(torch.randn(c, 2 * c, 3, 3, generator=g) / math.sqrt(18 * c), dtype)
+    b = torch.randn(c, generator=g) * 0.1
+    o1, o2, mask = raw.chunk(3, dim=1)
+    act = torch.cat([rb(10 * torch.tanh(torch.cat((o1, o2), dim=1)), dtype), rb(torch.sigmoid(mask), dtype)], dim=1)
+    off1, off2 = act[:, :18 * G].chunk(2, dim=1)
+    off1 = off1 + f1.permute(0, 3, 1, 2).flip(1).repeat(1, off1.shape[1] // 2, 1, 1)
+    off2 = off2 + f2.permute(0, 3, 1, 2).flip(1).repeat(1, off2.shape[1] // 2, 1, 1)
+    ref = deform_conv2d(x, torch.cat([off1, off2], 1), w, b, (1, 1), (1, 1), (1, 1), act[:, 18 * G:])
+    wp = ops.pack_conv_weight(w, [(2 * c, 2 * c)], dtype).to(dev)
+    y = ops.dcn_align(to_clip(x[:, :c], dtype, dev), to_clip(x[:, c:], dtype, dev),
+                      to_clip(act[:, ops.dcn_raw_permutation(G)], dtype, dev), f1.to(dev), f2.to(dev), wp, b.to(dev), c,
+                      raw_activated=True)
+    torch.cuda.synchronize()
+    assert_close(from_clip(y), ref, dtype, f"dcn activated c={c}", scale=2.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("path", ["halo", "igemm", "chain"])
+def test_dcn_offset_activation_epilogue(dev, dtype, path):
+    """FLAIR_ACT_DCN_OFFSETS in the epilogue of the offset convolution (tap-major output: per 48 channels
+    32 residues -> 10*tanh, 16 masks -> sigmoid), on the three kernels that can produce it."""
+    ops = _ops()
+    G, cin = 16, 64
+    H, W = (16, 32) if path != "igemm" else (12, 20)
+    g = torch.Generator().manual_seed(5)
+    x = rb(torch.randn(1, cin, H, W, generator=g), dtype)
+    w = rb(torch.randn(27 * G, cin, 3, 3, generator=g) / math.sqrt(9 * cin) * 3, dtype)
+    b = torch.randn(27 * G, generator=g) * 0.3
+    pre = F.conv2d(x, w, b, padding=1)
+    ch = torch.arange(27 * G)
+    residue = (ch % (3 * G)) < 2 * G
+    ref = torch.where(residue.view(1, -1, 1, 1), 10 * torch.tanh(pre), torch.sigmoid(pre))
+    wp = ops.pack_conv_weight(w[:, :, None], [(cin, cin)], dtype).to(dev)
+    xc = to_clip(x, dtype, dev)
+    if path == "chain":
+        y = ops.conv_chain(xc, None, None, 0, wp, b.to(dev), ops.ACT_DCN_OFFSETS, cin, 27 * G, act_param=10.0,
+                           act_period=3 * G)
+    else:
+        y = ops.conv(xc, wp, b.to(dev), 27 * G, (1, 3, 3), act=ops.ACT_DCN_OFFSETS, act_param=10.0, act_period=3 * G)
+    torch.cuda.synchronize()
+    # tanh / sigmoid through __expf + v_rcp: 1e-6 relative; the bound is on max|ref| = 10
+    assert_close(from_clip(y), ref, dtype, f"dcn offset activation ({path})", scale=2.0)
+
+
 def test_embedding_linear_layout(dev):
     from oracle.unet import timestep_embedding
     ops = _ops()
