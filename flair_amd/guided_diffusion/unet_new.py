@@ -231,11 +231,18 @@ class TemporalAttention(nn.Module):
         # positional codes of the window offsets and their images under W_q / W_k are
         # constants of the layer: fold them once (q bias, per-slot key bias).
         offs = torch.arange(f, dtype=torch.float32, device=device) - f // 2
-        pe = ops.timestep_embedding(offs, c)
         mid = f // 2
         wq, wk, wv = (_dev(m.weight, device) for m in (self.q_linear, self.k_linear, self.v_linear))
-        bq = ops.linear(pe[mid:mid + 1].contiguous(), wq, _dev(self.q_linear.bias, device))
-        kpos = ops.linear(torch.cat([pe[:mid], pe[mid + 1:]]).contiguous(), wk, None)
+        if torch.device(device).type == "cuda":
+            pe = ops.timestep_embedding(offs, c)
+            bq = ops.linear(pe[mid:mid + 1].contiguous(), wq, _dev(self.q_linear.bias, device))
+            kpos = ops.linear(torch.cat([pe[:mid], pe[mid + 1:]]).contiguous(), wk, None)
+        else:   # host-side packing (multi-process CPU tests of the weight blob): the same one-time folding in torch
+            freqs = torch.exp(-math.log(10000.0) * torch.arange(c // 2, dtype=torch.float32) / (c // 2))
+            ang = offs[:, None] * freqs[None]
+            pe = torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1)
+            bq = pe[mid:mid + 1] @ wq.t() + _dev(self.q_linear.bias, device)
+            kpos = torch.cat([pe[:mid], pe[mid + 1:]]) @ wk.t()
         wqkv = torch.cat([wq, wk, wv]).reshape(3 * c, c, 1, 1)
         bqkv = torch.cat([bq.reshape(-1), _dev(self.k_linear.bias, device), _dev(self.v_linear.bias, device)])
         self._pk = dict(

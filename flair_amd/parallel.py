@@ -53,6 +53,37 @@ def broadcast_weights(model, src=0, bucket_bytes=256 << 20):
     return time.perf_counter() - t0
 
 
+def broadcast_packed_weights(model, src=0, chunk_bytes=512 << 20):
+    """Start-up weight distribution in the kernels' own format: ``src`` packs once (bf16 [Cout][taps][Cin] conv
+    weights, batched embedding matrix, ...: flair_amd.checkpoint.export_packed) and broadcasts ONE flat blob
+    (0.83 GB for unet_new.UNetModel in bf16) in ``chunk_bytes`` messages -- RCCL over xGMI on the GPUs, gloo in
+    the CPU tests; the other ranks attach views of it to their model and never repack.  Replaces the reference's
+    pickled-chunk ``load_state_dict`` + per-parameter ``sync_params`` (dist_util.py:40-79) and halves the bytes of
+    ``broadcast_weights`` (which ships the fp32 masters).  Returns (seconds, blob bytes)."""
+    from . import checkpoint
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return 0.0, 0
+    t0 = time.perf_counter()
+    device = next(model.parameters()).device
+    rank = dist.get_rank()
+    if rank == src:
+        meta, blob = checkpoint.export_packed(model, device)
+        box = [meta]
+    else:
+        box = [None]
+    dist.broadcast_object_list(box, src=src)            # the description: a few hundred KB of python
+    meta = box[0]
+    if rank != src:
+        blob = torch.empty(meta["nbytes"], dtype=torch.uint8, device=device)
+    for off in range(0, meta["nbytes"], chunk_bytes):
+        dist.broadcast(blob[off:off + chunk_bytes], src=src)
+    if rank != src:
+        checkpoint.import_packed(model, meta, blob)
+    if blob.is_cuda:
+        torch.cuda.synchronize()
+    return time.perf_counter() - t0, int(meta["nbytes"])
+
+
 def gather_results(local_items, dst=0):
     """Collect per-rank python results (timings, file names) on ``dst`` (host-side gather)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:

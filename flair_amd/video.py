@@ -88,6 +88,40 @@ def rnn_input(degraded_norm_clip, size):
     return _affine(big, 1.0, 0.0, -1.0, 1.0)
 
 
+def restore_window(task, degraded01, model, diffusion, restore_fn_for, *, size, prev_recon=None, overlap=OVERLAP,
+                   window_index=0, aux_model=wl.identity_aux, vsrpp_weights_fn=None, hp=None, tau=5, t_start=-1,
+                   noise_fn=None, q_noise_fn=None):
+    """One window of the loop (video_sample.py:371-485).  degraded01: (1, T, 3, h, w) in [0, 1] on the GPU;
+    prev_recon: the previous window's last ``overlap`` results ((1, <=overlap, 3, S, S), [-1, 1] domain) or None.
+    Returns (frames01 of the frames this window contributes, (T', 3, S, S) in [0, 1]; next prev_recon)."""
+    hp = hp or wl.TASKS[task]
+    dev = degraded01.device
+    wi = window_index
+    deg = degraded01[0].float().contiguous()                                      # (T,3,h,w) in [0,1]
+    T = deg.shape[0]
+    init_n = init_frames(task, deg, size)[None]                                   # (1,T,3,S,S) in [-1,1]
+    deg_n, deg_n_clip = normalise(deg)
+    deg_n = deg_n[None]
+    t0 = diffusion.num_timesteps - 1 if t_start == -1 else t_start
+    tt = torch.full((T,), t0, device=dev, dtype=torch.long)
+    qn = q_noise_fn(wi, init_n[0]) if q_noise_fn is not None else None
+    noise = diffusion.q_sample(init_n[0].contiguous(), tt, noise=qn)
+    kwargs = dict(low_res_input=init_n, num_frames=T, enable_cross_frames=True,
+                  vsrpp_weights=vsrpp_weights_fn(init_n) if vsrpp_weights_fn is not None else 1.0)
+    if "bicubic" not in task:
+        kwargs["rnn_input"] = rnn_input(deg_n_clip, size)[None]
+    sample = diffusion.sample(
+        model, noise, model_kwargs=kwargs, device=dev, progress=False, clip_denoised=True,
+        restore_fn=restore_fn_for(deg_n), post_fn=None, face_restore_helper=None, aux_model=aux_model,
+        w=hp["w"], tau=tau, affine_matrices=None, aligned=True, sample_mode="ddpm", rho=hp["rho"],
+        noise_level=hp["noise_level"], prev_recon=prev_recon, zeta=hp["zeta"], t_start=t_start,
+        noise_fn=(lambda it, like, _wi=wi: noise_fn(_wi, it, like)) if noise_fn is not None else None)
+    keep = sample if prev_recon is None else sample[overlap:]                    # (T',3,S,S), [-1,1] domain
+    nxt = keep[-overlap:].clone()[None] if overlap > 0 else None                 # (1,<=overlap,3,S,S), :481-483
+    frames01 = _affine(_to_clip(keep.contiguous()), 0.5, 0.5, 0.0, 1.0)          # (clamp(x,-1,1)+1)/2
+    return frames01, nxt
+
+
 def restore_video(task, degraded01, model, diffusion, restore_fn_for, *, size, aux_model=wl.identity_aux,
                   vsrpp_weights_fn=None, hp=None, tau=5, t_start=-1, length=FRAME_SLICE_LEN, overlap=OVERLAP,
                   noise_fn=None, q_noise_fn=None):
@@ -96,36 +130,18 @@ def restore_video(task, degraded01, model, diffusion, restore_fn_for, *, size, a
     restore_fn_for(degraded_norm_window (1,T,3,h,w)) -> restore_fn(x0) is the data-consistency
     operator of the window (video_sample.py:455-459); vsrpp_weights_fn(init_norm (1,T,3,S,S)) supplies
     the per-pixel propagation weights of the bicubic tasks (face parsing, :427-444) and defaults to 1.0;
-    noise_fn / q_noise_fn(window_index, like) let tests share one noise tape with the oracle."""
-    hp = hp or wl.TASKS[task]
+    noise_fn / q_noise_fn(window_index, like) let tests share one noise tape with the oracle.
+    (File-to-file form with decode / upload / encode overlapped: flair_amd.io.restore_video_files.)"""
     dev = degraded01.device
     n_frames = degraded01.shape[1]
     prev_recon = None
     out = torch.empty((n_frames, 3, size, size), dtype=torch.float32, device=dev)
     filled = 0
     for wi, idx in enumerate(window_indices(n_frames, length, overlap)):
-        T = len(idx)
-        deg = degraded01[0, idx[0]:idx[-1] + 1].float().contiguous()            # (T,3,h,w) in [0,1]
-        init_n = init_frames(task, deg, size)[None]                               # (1,T,3,S,S) in [-1,1]
-        deg_n, deg_n_clip = normalise(deg)
-        deg_n = deg_n[None]
-        t0 = diffusion.num_timesteps - 1 if t_start == -1 else t_start
-        tt = torch.full((T,), t0, device=dev, dtype=torch.long)
-        qn = q_noise_fn(wi, init_n[0]) if q_noise_fn is not None else None
-        noise = diffusion.q_sample(init_n[0].contiguous(), tt, noise=qn)
-        kwargs = dict(low_res_input=init_n, num_frames=T, enable_cross_frames=True,
-                      vsrpp_weights=vsrpp_weights_fn(init_n) if vsrpp_weights_fn is not None else 1.0)
-        if "bicubic" not in task:
-            kwargs["rnn_input"] = rnn_input(deg_n_clip, size)[None]
-        sample = diffusion.sample(
-            model, noise, model_kwargs=kwargs, device=dev, progress=False, clip_denoised=True,
-            restore_fn=restore_fn_for(deg_n), post_fn=None, face_restore_helper=None, aux_model=aux_model,
-            w=hp["w"], tau=tau, affine_matrices=None, aligned=True, sample_mode="ddpm", rho=hp["rho"],
-            noise_level=hp["noise_level"], prev_recon=prev_recon, zeta=hp["zeta"], t_start=t_start,
-            noise_fn=(lambda it, like, _wi=wi: noise_fn(_wi, it, like)) if noise_fn is not None else None)
-        keep = sample if prev_recon is None else sample[overlap:]                # (T',3,S,S), [-1,1] domain
-        prev_recon = keep[-overlap:].clone()[None] if overlap > 0 else None      # (1,<=overlap,3,S,S), :481-483
-        frames01 = _affine(_to_clip(keep.contiguous()), 0.5, 0.5, 0.0, 1.0)      # (clamp(x,-1,1)+1)/2
+        frames01, prev_recon = restore_window(
+            task, degraded01[:, idx[0]:idx[-1] + 1], model, diffusion, restore_fn_for, size=size,
+            prev_recon=prev_recon, overlap=overlap, window_index=wi, aux_model=aux_model,
+            vsrpp_weights_fn=vsrpp_weights_fn, hp=hp, tau=tau, t_start=t_start, noise_fn=noise_fn, q_noise_fn=q_noise_fn)
         out[filled:filled + frames01.shape[0]].copy_(frames01)
         filled += frames01.shape[0]
     return out[:filled]

@@ -197,3 +197,42 @@ def test_unet_call_variants_vs_oracle(dev):
         torch.cuda.synchronize()
         err = (y.cpu() - ref).abs().max().item() / ref.abs().max().item()
         assert err <= 2e-4, (list(kw), err)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("family", ["unet_new", "sr3"])
+def test_packed_weight_blob_gives_identical_forward(dev, family):
+    """flair_amd.checkpoint.export_packed / import_packed: a model with DIFFERENT fp32 parameters that is handed
+    the source model's kernel-native blob (what broadcast_packed_weights ships) computes bit-identical outputs
+    without repacking (f3 / section 8e)."""
+    from flair_amd import checkpoint
+    if family == "unet_new":
+        from flair_amd.guided_diffusion.unet_new import UNetModel as Net
+        cfg = SMALL
+        T, S = 3, 32
+        x, lr, t = _inputs(T, S)
+        call = lambda m: m(x.to(dev), t.to(dev), low_res_input=lr.to(dev), num_frames=T, vsrpp_weights=1.0)   # noqa: E731
+    else:
+        from flair_amd.guided_diffusion.sr3 import UNet as Net
+        from tests.test_gpu_sr3 import SR3_SMALL as cfg, inputs
+        x, lr, level = inputs(T=3, S=64)
+        call = lambda m: m(x.to(dev), level.to(dev), low_res_input=lr.to(dev), num_frames=3, vsrpp_weights=0.93)   # noqa: E731
+    torch.manual_seed(0)
+    a = Net(**cfg).to(dev).eval()
+    torch.manual_seed(1)
+    b = Net(**cfg).to(dev).eval()
+    for m in (a, b):
+        with torch.no_grad():
+            for p in m.parameters():
+                if p.abs().sum() == 0:
+                    p.normal_(0, 0.02)
+        m.convert_to_fp16()
+    ya = call(a)
+    assert not torch.equal(ya, call(b))
+    meta, blob = checkpoint.export_packed(a)
+    checkpoint.import_packed(b, meta, blob.clone())
+    yb = call(b)
+    torch.cuda.synchronize()
+    assert torch.equal(ya, yb)
+    masters = sum(p.numel() * 4 for p in a.parameters())
+    assert blob.numel() < 0.75 * masters

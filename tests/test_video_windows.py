@@ -108,3 +108,93 @@ def test_restore_video_matches_oracle_loop(dev):
     assert got.shape == (N, 3, S, S)
     err = (got.cpu() - ref).abs().max().item()
     assert err <= 5e-4, err          # f32 elementwise chain (same bound as the sampler trajectory test)
+
+
+def _write_pngs(tmp_path, n, s, seed=5):
+    import numpy as np
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    names = [f"frame_{i}.png" for i in range(n)]           # natural order differs from lexicographic order (10 < 2)
+    frames = []
+    for nm in names:
+        arr = rng.integers(0, 256, size=(s, s, 3), dtype=np.uint8)
+        Image.fromarray(arr, mode="RGB").save(tmp_path / nm)
+        frames.append(arr)
+    (tmp_path / "notes.txt").write_text("not a frame")
+    return names, frames
+
+
+def test_frame_files_round_trip(tmp_path):
+    """flair_amd.io: the reference's glob + natural order (video_sample.py:334), decode to (1,N,3,h,w) float/255
+    (:337-345), and ``(x*255).byte()`` -> PNG (:487-492) give back the same bytes."""
+    import numpy as np
+    from PIL import Image
+    from flair_amd import io as fio
+    names, frames = _write_pngs(tmp_path, 12, 8)
+    paths = fio.list_frames(tmp_path)
+    assert [p.split("/")[-1] for p in paths] == names      # frame_2 before frame_10, notes.txt excluded
+    x = fio.read_frames(paths)
+    assert x.shape == (1, 12, 3, 8, 8) and x.dtype == torch.float32
+    assert torch.equal((x[0] * 255).round().byte(), torch.from_numpy(np.stack(frames)).permute(0, 3, 1, 2))
+    u8 = fio.to_bytes(x[0])
+    assert u8.shape == (12, 8, 8, 3)
+    w = fio._Writer(tmp_path / "out")
+    w.submit(0, x[0][:7])
+    w.submit(7, x[0][7:])
+    w.close()
+    back = [np.asarray(Image.open(tmp_path / "out" / f"{i:04d}.png")) for i in range(12)]
+    # float/255*255 truncates to v or v-1 (the reference's own behaviour: it never rounds, :489)
+    assert all(np.abs(b.astype(int) - f.astype(int)).max() <= 1 for b, f in zip(back, frames))
+    assert all(np.array_equal(b, np.asarray(u8[i])) for i, b in enumerate(back))
+
+
+def test_iter_windows_on_host(tmp_path):
+    """The streaming window iterator (decode-ahead thread) yields the windows of window_indices with the
+    same frames read_frames gives, each shared frame decoded once."""
+    from flair_amd import io as fio
+    from flair_amd.video import window_indices
+    _write_pngs(tmp_path, 9, 6)
+    paths = fio.list_frames(tmp_path)
+    full = fio.read_frames(paths)
+    got = list(fio.iter_windows(paths, "cpu", length=4, overlap=1))
+    assert [idx for idx, _ in got] == window_indices(9, 4, 1)
+    for idx, x in got:
+        assert torch.equal(x, full[:, idx[0]:idx[-1] + 1])
+
+
+@pytest.mark.gpu
+def test_restore_video_files_matches_in_memory(dev, tmp_path):
+    """File-to-file streaming harness == the in-memory loop on the same frames (toy network, 4-step chain)."""
+    import numpy as np
+    from PIL import Image
+    from flair_amd import io as fio
+    from flair_amd import video
+    from flair_amd import workload as wl
+    from flair_amd.guided_diffusion import pseudoSR as psr
+    N, s, S, L, OV, steps = 7, 8, 32, 4, 1, 4
+    _write_pngs(tmp_path, N, s)
+    paths = fio.list_frames(tmp_path)
+    degraded = fio.read_frames(paths).to(dev)
+    g = torch.Generator().manual_seed(3)
+    wins = video.window_indices(N, L, OV)
+    tapes = [[torch.randn(len(w), 3, S, S, generator=g).to(dev) for _ in range(steps)] for w in wins]
+    qnoise = [torch.randn(len(w), 3, S, S, generator=g).to(dev) for w in wins]
+    diffusion = wl.diffusion_for(steps)
+    A = psr.pseudoSR(psr.Get_pseudoSR_Conf(4), upscale_kernel=wl.synthetic_blur_kernel(),
+                     kernel_indx=10).WrapArchitecture_PyTorch().to(dev)
+
+    class M:
+        def parameters(self):
+            return iter([degraded])
+
+        def __call__(self, x, t, **kw):
+            return _toy_model(x, t, **kw)
+    common = dict(size=S, tau=1, length=L, overlap=OV, noise_fn=lambda wi, it, like: tapes[wi][it],
+                  q_noise_fn=lambda wi, like: qnoise[wi])
+    rf = lambda d_n: (lambda x0: A.A_pinv(d_n[0].contiguous(), x0))      # noqa: E731
+    ref = video.restore_video("gaussian", degraded, M(), diffusion, rf, **common)
+    n = fio.restore_video_files("gaussian", tmp_path, tmp_path / "out", M(), diffusion, rf, device=dev, **common)
+    assert n == N
+    want = fio.to_bytes(ref).cpu().numpy()
+    for i in range(N):
+        assert np.array_equal(np.asarray(Image.open(tmp_path / "out" / f"{i:04d}.png")), want[i])
