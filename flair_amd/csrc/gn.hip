@@ -19,6 +19,8 @@
 //                 mean/rstd/gamma/beta/(scale,shift); optionally writes the 2x2
 //                 average-pooled or nearest-upsampled result and the resampled
 //                 raw input in the same pass.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -348,7 +350,10 @@ extern "C" int flair_groupnorm_nhwc(const flair_gn_params* p, const void* x0, co
     a.y = y; a.yLd = p->y_ld; a.raw = raw; a.rawLd = p->raw_ld;
     const long outPix = p->resample == 1 ? (long)p->H * p->W / 4 : (long)p->H * p->W;
     int bpf = (int)((outPix + (long)rows * 4 - 1) / ((long)rows * 4));
-    const int maxBpf = 4096 / p->F > 0 ? 4096 / p->F : 1;
+    // ~4 workgroups per CU, each streaming a long pixel range: measured on the 16x256^2x64 / 16x128^2x128 clip
+    // tensors 4096 blocks 105 / 101 us, 1024 blocks 91 / 63 us for the whole norm (tools/bench_gn.py, r02)
+    static const int totalBlocks = getenv("FLAIR_GN_BLOCKS") ? atoi(getenv("FLAIR_GN_BLOCKS")) : 1024;
+    const int maxBpf = totalBlocks / p->F > 0 ? totalBlocks / p->F : 1;
     if (bpf > maxBpf) bpf = maxBpf;
     if (bpf < 1) bpf = 1;
     a.blocksPerFrame = bpf;
