@@ -167,6 +167,48 @@ __global__ void vsrpp_prep_kernel(const E* prop, int propLd, const E* feat2, int
     }
 }
 
+// Two independent warps of one propagation step with BOTH flows given (the second-order flow
+// flow1 + warp(flow_prev, flow1) depends on the flows only, so the caller composes it once per clip
+// instead of once per denoising step): cond1 = warp(prop, flow1), cond2 = warp(feat2, flow2).
+// blockIdx.y selects the warp, so the two gather chains run side by side instead of one after the other.
+template <typename E>
+__global__ void vsrpp_warp2_kernel(const E* prop, int propLd, const E* feat2, int feat2Ld, const float* flow1,
+                                   const float* flow2, int H, int W, int C, E* cond1, int cond1Ld, E* cond2,
+                                   int cond2Ld) {
+    constexpr int VEC = ET<E>::VEC;
+    const int cv = C / VEC;
+    const long total = (long)H * W * cv;
+    const bool second = blockIdx.y == 1;
+    const E* src = second ? feat2 : prop;
+    const int srcLd = second ? feat2Ld : propLd;
+    const float* flow = second ? flow2 : flow1;
+    E* dst = second ? cond2 : cond1;
+    const int dstLd = second ? cond2Ld : cond1Ld;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % cv) * VEC;
+        const long p = i / cv;
+        const int w = (int)(p % W), h = (int)(p / W);
+        const float2 f = *reinterpret_cast<const float2*>(flow + p * 2);
+        int xy[2];
+        float wg[4];
+        bil_setup((float)w + f.x, (float)h + f.y, W, H, xy, wg);
+        float acc[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int xx = xy[0] + (q & 1), yy = xy[1] + (q >> 1);
+            if ((unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H) {
+                float v[VEC];
+                Vec16<E>::load(src + ((long)yy * W + xx) * srcLd + c0, v);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[k] = fmaf(wg[q], v[k], acc[k]);
+            }
+        }
+        Vec16<E>::store(dst + p * dstLd + c0, acc);
+    }
+}
+
 // ---- generic scalar-channel resize (few channels: images and flows) ------------------
 __device__ __forceinline__ float cubic1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
 __device__ __forceinline__ float cubic2(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
@@ -289,6 +331,27 @@ extern "C" int flair_resize_nhwc(const void* x, int dtype, int x_ld, int F, int 
                            Hi, Wi, C, mode, Ho, Wo, (float*)y, y_ld, scale_c0, scale_c1);
     else
         FLAIR_CHECK(false, "flair_resize_nhwc: bad dtype");
+    FLAIR_LAUNCH_CHECK();
+    return FLAIR_OK;
+}
+
+extern "C" int flair_vsrpp_warp2(const void* prop, int prop_ld, const void* feat2, int feat2_ld, const float* flow1,
+                                 const float* flow2, int dtype, int H, int W, int C, void* cond1, int cond1_ld,
+                                 void* cond2, int cond2_ld, hipStream_t stream) {
+    FLAIR_CHECK(prop && flow1 && cond1 && H > 0 && W > 0 && C > 0, "flair_vsrpp_warp2: bad argument");
+    FLAIR_CHECK(!flow2 || (feat2 && cond2), "flair_vsrpp_warp2: second-order inputs incomplete");
+    const int vec = dtype == FLAIR_BF16 ? 8 : 4;
+    FLAIR_CHECK(dtype == FLAIR_BF16 || dtype == FLAIR_F32, "flair_vsrpp_warp2: bad dtype");
+    FLAIR_CHECK(C % vec == 0, "flair_vsrpp_warp2: C %% %d", vec);
+    const dim3 grid(grid_for((long)H * W * (C / vec)), flow2 ? 2 : 1);
+    if (dtype == FLAIR_BF16)
+        hipLaunchKernelGGL(vsrpp_warp2_kernel<bf16_t>, grid, dim3(256), 0, stream, (const bf16_t*)prop, prop_ld,
+                           (const bf16_t*)feat2, feat2_ld, flow1, flow2, H, W, C, (bf16_t*)cond1, cond1_ld,
+                           (bf16_t*)cond2, cond2_ld);
+    else
+        hipLaunchKernelGGL(vsrpp_warp2_kernel<float>, grid, dim3(256), 0, stream, (const float*)prop, prop_ld,
+                           (const float*)feat2, feat2_ld, flow1, flow2, H, W, C, (float*)cond1, cond1_ld,
+                           (float*)cond2, cond2_ld);
     FLAIR_LAUNCH_CHECK();
     return FLAIR_OK;
 }

@@ -415,6 +415,7 @@ class UNet(nn.Module):
                 ops.affine_channels(raw, 3, 0.5, 0.5, 0.0, 1.0, sp._pk["mean"], sp._pk["istd"], norm)
                 a, b = norm[:-1], norm[1:]
                 flows[r] = (sp.run(b, a), sp.run(a, b))       # (forward, backward)
+            flows["_prop"] = {}              # per-clip store of composed second-order flows (BasicVSRPP._propagate)
             if len(self._flow_cache) >= 16:
                 self._flow_cache.clear()
             hit = (flows, rnn_clip)

@@ -297,6 +297,7 @@ import os as _os
 
 USE_CHAIN = _os.environ.get("FLAIR_CHAIN", "1") != "0"          # A/B switches for same-box comparisons
 ACT_IN_OFFSET_CONV = _os.environ.get("FLAIR_DCN_ACT", "1") != "0"
+CACHE_FLOW2 = _os.environ.get("FLAIR_FLOW2_CACHE", "1") != "0"
 
 
 def run_trunk(pk, segs, c, *, extra_res=None, out=None, out_scale=1.0):
@@ -385,25 +386,36 @@ class BasicVSRPP(nn.Module):
             flow_idx = order
         zero_c = torch.zeros((1, H, W, c), dtype=ctx.dtype, device=ctx.device)
         ka = ops.k_align(ctx.dtype)
-        flowpad = torch.zeros((1, H, W, ka), dtype=ctx.dtype, device=ctx.device)
         k3 = (1, 3, 3)
         G = self.deform_align[name].deform_groups
         mag = float(self.deform_align[name].max_residue_magnitude)
+        # The second-order flows flow_n1 + warp(flow_prev, flow_n1) (unet_new.py:716-718) and the 4-channel flow
+        # segment of conv_offset[0]'s input depend on the optical flows alone: they are composed on the first
+        # denoising step of a clip and kept with the cached flows (shared by every module of this resolution).
+        store = ctx.flows.get("_prop") if (CACHE_FLOW2 and isinstance(ctx.flows, dict)) else None
+        key = (name, H, W, ctx.dtype, ka)
+        cached = store.get(key) if store is not None else None
+        fill = [] if (cached is None and store is not None) else None
         prop, prev2 = zero_c, None     # prop: feature of the previous step; prev2: the one before
         for i, idx in enumerate(order):
             cur = hidden[idx:idx + 1]
             if i > 0:
                 flow_n1 = flows[flow_idx[i]:flow_idx[i] + 1]
                 cond_n1 = torch.empty_like(zero_c)
-                if i > 1:
-                    feat_n2 = prev2
-                    cond_n2 = torch.empty_like(zero_c)
-                    flow_n2 = torch.empty_like(flow_n1)
-                    ops.vsrpp_prep(prop, feat_n2, flow_n1, flows[flow_idx[i - 1]:flow_idx[i - 1] + 1],
-                                   cond_n1, cond_n2, flow_n2, flowpad)
+                second = i > 1
+                feat_n2 = prev2 if second else zero_c
+                cond_n2 = torch.empty_like(zero_c) if second else zero_c
+                if cached is not None:
+                    flow_n2, flowpad = cached[i - 1]
+                    ops.vsrpp_warp2(prop, feat_n2 if second else None, flow_n1, flow_n2, cond_n1, cond_n2 if second else None)
                 else:
-                    feat_n2, flow_n2, cond_n2 = zero_c, None, zero_c
-                    ops.vsrpp_prep(prop, None, flow_n1, None, cond_n1, None, None, flowpad)
+                    flowpad = torch.zeros((1, H, W, ka), dtype=ctx.dtype, device=ctx.device)
+                    flow_n2 = torch.empty_like(flow_n1) if second else None
+                    ops.vsrpp_prep(prop, feat_n2 if second else None, flow_n1,
+                                   flows[flow_idx[i - 1]:flow_idx[i - 1] + 1] if second else None,
+                                   cond_n1, cond_n2 if second else None, flow_n2, flowpad)
+                    if fill is not None:
+                        fill.append((flow_n2, flowpad))
                 o = ops.conv([cond_n1, cur, cond_n2, flowpad], pk_a["w0"], pk_a["b0"], c, k3, act=A.ACT_LRELU01)
                 if USE_CHAIN and c == 64 and ops.chain_supported(o, c):
                     o = ops.conv_chain(o, pk_a["w2"], pk_a["b2"], A.ACT_LRELU01, pk_a["w4"], pk_a["b4"],
@@ -428,6 +440,8 @@ class BasicVSRPP(nn.Module):
             if wmaps is not None:
                 ops.scale_pixels(new, wmaps[idx])
             prev2, prop = (prop if i > 0 else None), new
+        if fill is not None:
+            store[key] = fill
         return dest
 
     def run(self, ctx, hidden):
@@ -758,6 +772,7 @@ class UNetModel(nn.Module):
                 if w != r:
                     src = ops.resize(raw, (r, r), ops.RESIZE_BICUBIC, channels=3)
                 flows[r] = self._flows_from_clip(src)
+            flows["_prop"] = {}              # per-clip store of composed second-order flows (BasicVSRPP._propagate)
             if len(self._flow_cache) >= 16:
                 self._flow_cache.clear()
             hit = (flows, rnn_clip)          # keep the keyed storage alive
@@ -795,6 +810,11 @@ class UNetModel(nn.Module):
         # conditioning identity: storage + torch version + the sampler's chain counter (kernels launched
         # through ctypes do not bump _version, so every new chain refreshes conditioning and flows once)
         src = (rnn.data_ptr(), rnn._version, low_res.data_ptr(), low_res._version, getattr(self, "_flow_gen", 0))
+        if ent is not None and ent["src"] != src:
+            # a new clip / chain: the captured launches read this clip's flows AND the second-order flows composed
+            # from them (BasicVSRPP._propagate's per-clip store): re-capture (one eager forward, once per chain)
+            del self._graphs[key]
+            ent = None
         if ent is None:
             st = dict(x=x.clone(), t=t.clone(), lr=low_res.clone(), rnn=rnn.clone())
             flows = self._flows_for(st["rnn"])               # SPyNet runs eagerly, before capture
@@ -813,16 +833,6 @@ class UNetModel(nn.Module):
             ent = dict(graph=graph, st=st, out=out, src=src, flows=flows)
             self._graphs[key] = ent
         st = ent["st"]
-        if ent["src"] != src:                                # a new clip / chain: refresh conditioning + flows
-            st["lr"].copy_(low_res)
-            st["rnn"].copy_(rnn)
-            self._flow_cache.pop((st["rnn"].data_ptr(), st["rnn"]._version, tuple(st["rnn"].shape)), None)
-            new = self._flows_for(st["rnn"])
-            for r, pair in ent["flows"].items():             # the graph reads the flow buffers it captured
-                for o, n in zip(pair, new[r]):
-                    if o is not n:
-                        o.copy_(n)
-            ent["src"] = src
         st["x"].copy_(x)
         st["t"].copy_(t)
         ent["graph"].replay()

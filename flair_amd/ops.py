@@ -640,6 +640,20 @@ def vsrpp_prep(prop, feat2, flow1, flow_prev, cond1, cond2, flow2_out, flowpad):
         _prof_end(e0, ("prep",), prop.dtype, 0.0, prop.element_size() * H * W * (2.0 * n * C + flowpad.shape[3]) + 8.0 * H * W * n)
 
 
+def vsrpp_warp2(prop, feat2, flow1, flow2, cond1, cond2):
+    """cond1 = warp(prop, flow1), cond2 = warp(feat2, flow2) in one launch (flair_vsrpp_warp2); flows precomposed."""
+    _, H, W, C = prop.shape
+    second = flow2 is not None
+    e0 = _prof_begin()
+    check(lib().flair_vsrpp_warp2(ptr(prop), _ld(prop), ptr(feat2 if second else None), _ld(feat2) if second else 0,
+                                  ptr(_f32(flow1)), ptr(_f32(flow2) if second else None), dtype_code(prop), H, W, C,
+                                  ptr(cond1), _ld(cond1), ptr(cond2 if second else None), _ld(cond2) if second else 0,
+                                  stream()), "flair_vsrpp_warp2")
+    if e0 is not None:
+        n = 2 if second else 1
+        _prof_end(e0, ("prep",), prop.dtype, 0.0, prop.element_size() * H * W * 2.0 * n * C + 8.0 * H * W * n)
+
+
 def gated_blend(x, m, gate, out=None):
     """x + sigmoid(gate[f, c]) * (m - x); gate: (F, >=C) f32 logits."""
     T, H, W, C = x.shape

@@ -280,6 +280,13 @@ int flair_flow_warp(const void* x, int dtype, int x_ld, const float* flow, int f
 /* out = f1 + warp(f2, f1) on flow fields (unet_new.py:716-718). */
 int flair_flow_compose(const float* f1, const float* f2, int F, int H, int W, float* out,
                        hipStream_t stream);
+/* The two warps of one BasicVSR++ propagation step with both flows given (unet_new.py:706,719):
+ * cond1 = warp(prop, flow1), cond2 = warp(feat2, flow2); flow2 == NULL: first-order step (cond1 only).
+ * The second-order flow (unet_new.py:716-718) depends on the optical flows alone, so the caller composes it
+ * once per clip (flair_vsrpp_prep on the first denoising step) and reuses it for the other steps. */
+int flair_vsrpp_warp2(const void* prop, int prop_ld, const void* feat2, int feat2_ld, const float* flow1,
+                      const float* flow2, int dtype, int H, int W, int C, void* cond1, int cond1_ld,
+                      void* cond2, int cond2_ld, hipStream_t stream);
 /* One BasicVSR++ propagation step's alignment inputs in one launch (unet_new.py:704-722):
  * cond1 = warp(prop, flow1); flow2 = flow1 + warp(flow_prev, flow1); cond2 = warp(feat2, flow2);
  * flowpad[p][0..3] = (flow1, flow2) in the activation dtype.  flow_prev == NULL: first-order
