@@ -185,7 +185,10 @@ def test_group_norm(dev, dtype, case):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("new_order", [False, True])
-@pytest.mark.parametrize("case", [(2, 4, 4, 2), (3, 8, 8, 4), (2, 16, 16, 4), (1, 32, 32, 1), (1, 12, 12, 2)])
+@pytest.mark.parametrize("case", [(2, 4, 4, 2), (3, 8, 8, 4), (2, 16, 16, 4), (1, 32, 32, 1), (1, 12, 12, 2),
+                                  (16, 16, 16, 4),      # the L = 256 blocks of config 2 (64-query workgroups)
+                                  (16, 32, 32, 4),      # L = 1024 (512x512 clips): 128-query workgroups, 16 KV tiles
+                                  (5, 20, 20, 13)])     # L = 400: last KV tile partly masked, 128-query workgroups
 def test_qkv_attention(dev, dtype, new_order, case):
     from oracle.unet import qkv_attention_legacy, qkv_attention_new
     ops = _ops()

@@ -43,7 +43,7 @@ def main():
         us = e0.elapsed_time(e1) * 1e3 / n
         flops = 4.0 * F_ * heads * L * L * 64
         tf = flops / us / 1e6
-        rows.append({"shape": name, "frames": F_, "L": L, "heads": heads, "workgroups": ((L + 127) // 128) * F_ * heads,
+        rows.append({"shape": name, "frames": F_, "L": L, "heads": heads, "workgroups": ((L + 127) // 128) * F_ * heads if ((L + 127) // 128) * F_ * heads >= 256 else ((L + 63) // 64) * F_ * heads,
                      "us_per_launch": us, "GFLOP": flops / 1e9, "TFLOP_s": tf, "frac_of_2.5PF": tf / PEAK_TFLOPS})
         print(f"{name:52s} {us:8.1f} us  {tf:8.1f} TFLOP/s = {tf / PEAK_TFLOPS:6.3f} of peak "
               f"({rows[-1]['workgroups']} workgroups)", flush=True)
