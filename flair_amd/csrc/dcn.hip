@@ -112,7 +112,9 @@ __device__ __forceinline__ float fast_tanh(float x) {
 // buffer resources cover exactly one frame, so rows above / below the image fall outside the resource and read 0
 // by the hardware range check; columns left / right of it get weight 0.  That removes the per-corner address
 // selects of the general path (the kernel is VALU-issue bound: ~75 % VALU-active, profiles/r02b_dcn_pmc_sq.txt).
-template <typename E, int NCF, int NPF, int TPP, bool ACTIVATED, bool ONEFRAME>
+// PFD = gather register sets in flight (2: the loads of step k+1 fly while step k is blended; 3: also step k+2 --
+// for the c = 128 tiles, where only 8 wavefronts per CU exist to hide the gather round trip).
+template <typename E, int NCF, int NPF, int TPP, bool ACTIVATED, bool ONEFRAME, int PFD>
 __global__ __launch_bounds__(32 * NPF * TPP, (NCF >= 4 ? 32 * NPF * TPP / 256 : 4)) void dcn_kernel(DcnArgs a) {
     constexpr int NT = 32 * NPF * TPP, NW = NT / 64;
     constexpr int TP = 32 * NPF, TC = 32 * NCF, CPR = TPP;
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(32 * NPF * TPP, (NCF >= 4 ? 32 * NPF * TPP / 256 : 
         uint4 c[4];
         uint4 w[WR];
         float wt[4];
-    } rs[2];
+    } rs[PFD];
 
     // per-thread part of the weight offsets (fixed over the K loop)
     unsigned wrow[WR];
@@ -328,48 +330,53 @@ __global__ __launch_bounds__(32 * NPF * TPP, (NCF >= 4 ? 32 * NPF * TPP / 256 : 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-    // Tap T's raw values are staged in the post-barrier phase of step T*cbPerTap - 3: after
-    // the last reader of that LDS buffer (tap T-2, top of step (T-1)*cbPerTap - 1) and with one
-    // barrier to go before their first reader (top of step T*cbPerTap - 1).
-    stage_raw(0);
-    int stageTap = 1;
-    if (cbPerTap < 3) {
-        stage_raw(1);
-        stageTap = 2;
-    }
-    int stageAt = stageTap * cbPerTap - 3;
+    // Tap T's raw values are staged in the post-barrier phase of step T*cbPerTap - (PFD+1): after the last reader of
+    // that LDS buffer (tap T-2, issued PFD-1 steps ahead) and with one barrier to go before their first reader
+    // (the issue for the first step of tap T, at the top of step T*cbPerTap - (PFD-1)).
+    constexpr int LEAD = PFD + 1;
+    int stageTap = 0;
+    while (stageTap < 2 && stageTap * cbPerTap - LEAD < 0) stage_raw(stageTap++);      // taps 0 (and 1) before the loop
+    int stageAt = stageTap * cbPerTap - LEAD;
     __syncthreads();
-    issue(rs[0]);
-    for (int k = 0; k < nk; k += 2) {
+    auto mfma_step = [&](int buf) {
+        const char* wb = stile + buf * BUF;
+        const char* xb = wb + TC * CPR * 16;
 #pragma unroll
-        for (int par = 0; par < 2; ++par) {
-            if (k + par + 1 < nk) issue(rs[par ^ 1]);
-            blend_and_stage(rs[par], par);
-            __syncthreads();
-            const char* wb = stile + par * BUF;
-            const char* xb = wb + TC * CPR * 16;
+        for (int i = 0; i < PAIRS; ++i) {
+            const int pair = KSPLIT > 1 ? wave % NPAIR : wave * PAIRS + i;
+            const int kpart = KSPLIT > 1 ? wave / NPAIR : 0;
+            const int pfrag = pair % NPF, cf = pair / NPF;
 #pragma unroll
-            for (int i = 0; i < PAIRS; ++i) {
-                const int pair = KSPLIT > 1 ? wave % NPAIR : wave * PAIRS + i;
-                const int kpart = KSPLIT > 1 ? wave / NPAIR : 0;
-                const int pfrag = pair % NPF, cf = pair / NPF;
+            for (int kk = 0; kk < KSUB; ++kk) {
+                const int ks = kpart * KSUB + kk;
+                uint4 af[2], bf[2];
 #pragma unroll
-                for (int kk = 0; kk < KSUB; ++kk) {
-                    const int ks = kpart * KSUB + kk;
-                    uint4 af[2], bf[2];
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int ch = ks * 4 + MmaD<E>::chunk(h, lh);
-                        bf[h] = *reinterpret_cast<const uint4*>(xb + tile_off<CPR>(pfrag * 32 + lr, ch));
-                        af[h] = *reinterpret_cast<const uint4*>(wb + tile_off<CPR>(cf * 32 + lr, ch));
-                    }
-                    MmaD<E>::run(af, bf, acc[i]);
+                for (int h = 0; h < 2; ++h) {
+                    const int ch = ks * 4 + MmaD<E>::chunk(h, lh);
+                    bf[h] = *reinterpret_cast<const uint4*>(xb + tile_off<CPR>(pfrag * 32 + lr, ch));
+                    af[h] = *reinterpret_cast<const uint4*>(wb + tile_off<CPR>(cf * 32 + lr, ch));
                 }
+                MmaD<E>::run(af, bf, acc[i]);
             }
-            if (k + par == stageAt && stageTap < 9) {
-                stage_raw(stageTap);
-                ++stageTap;
-                stageAt += cbPerTap;
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < PFD - 1; ++u)
+        if (u < nk) issue(rs[u]);
+    constexpr int UNR = 2 * PFD;                       // register sets cycle mod PFD, LDS tile buffers mod 2
+    for (int k = 0; k < nk; k += UNR) {
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (k + u < nk) {                          // block-uniform
+                if (k + u + PFD - 1 < nk) issue(rs[(u + PFD - 1) % PFD]);
+                blend_and_stage(rs[u % PFD], u & 1);
+                __syncthreads();
+                mfma_step(u & 1);
+                if (k + u == stageAt && stageTap < 9) {
+                    stage_raw(stageTap);
+                    ++stageTap;
+                    stageAt += cbPerTap;
+                }
             }
         }
     }
@@ -427,6 +434,7 @@ __global__ __launch_bounds__(32 * NPF * TPP, (NCF >= 4 ? 32 * NPF * TPP / 256 : 
 
 template <typename E, int NCF, int NPF, int TPP, bool ACTIVATED, bool ONEFRAME>
 static int launch_dcn_v(const DcnArgs& a0, hipStream_t stream) {
+    constexpr int PFD = NCF >= 4 ? 3 : 2;
     DcnArgs a = a0;
     if (ONEFRAME) {      // resources cover one frame: rows outside the image fall outside the resource
         const unsigned long long half = a.Cin / 2, hw = (unsigned long long)a.H * a.W;
@@ -438,12 +446,12 @@ static int launch_dcn_v(const DcnArgs& a0, hipStream_t stream) {
     const size_t lds = (size_t)2 * TP * rawPitch + 2 * (TC + TP) * TPP * 16;
     static bool attr = false;
     if (!attr) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_kernel<E, NCF, NPF, TPP, ACTIVATED, ONEFRAME>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_kernel<E, NCF, NPF, TPP, ACTIVATED, ONEFRAME, PFD>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         FLAIR_CHECK(e == hipSuccess, "flair_dcn_align: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr = true;
     }
-    hipLaunchKernelGGL((dcn_kernel<E, NCF, NPF, TPP, ACTIVATED, ONEFRAME>), dim3(cdiv(a.P, TP)), dim3(NT), lds, stream, a);
+    hipLaunchKernelGGL((dcn_kernel<E, NCF, NPF, TPP, ACTIVATED, ONEFRAME, PFD>), dim3(cdiv(a.P, TP)), dim3(NT), lds, stream, a);
     FLAIR_LAUNCH_CHECK();
     return FLAIR_OK;
 }
