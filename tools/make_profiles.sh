@@ -8,7 +8,7 @@ export PYTHONPATH=$R
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
-timeout -k 10 500 python bench.py > $OUT/bench_full.json 2> $OUT/bench_full.err
+timeout -k 10 900 python bench.py > $OUT/bench_full.json 2> $OUT/bench_full.err
 tail -1 $OUT/bench_full.json | cut -c1-300
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof /tmp/pmc_fetch /tmp/pmc_write
@@ -16,9 +16,15 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/prof -o p --output-fo
 cp /tmp/prof/p_kernel_stats.csv $OUT/bench_steps6_kernel_stats.csv
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pmc_fetch -o b --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pmc_write -o b --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-python $R/tools/pmc_traffic.py /tmp/pmc_fetch /tmp/pmc_write > $OUT/hbm_traffic_pmc.txt
+python $R/tools/pmc_traffic.py /tmp/pmc_fetch /tmp/pmc_write $OUT/hbm_traffic_pmc.json > $OUT/hbm_traffic_pmc.txt
 cd $R
 timeout -k 10 300 python bench.py --task x8_bicubic --no-cpu-baseline > $OUT/bench_x8_bicubic.json 2>/dev/null
 timeout -k 10 300 python bench.py --task jpeg --no-cpu-baseline > $OUT/bench_jpeg.json 2>/dev/null
 tail -1 $OUT/bench_x8_bicubic.json | cut -c1-200
 tail -1 $OUT/bench_jpeg.json | cut -c1-200
+python tools/bench_attn.py --json $OUT/attn_isolated.json > $OUT/attn_isolated.txt 2>/dev/null
+python tools/bench_gn.py > $OUT/gn_isolated.txt 2>/dev/null
+python tools/bench_dcn.py > $OUT/dcn_isolated.txt 2>/dev/null
+python tools/bench_chain.py > $OUT/chain_isolated.txt 2>/dev/null
+bash tools/ab_bench.sh $OUT/ab > /dev/null 2>&1
+cat $OUT/ab/ab.log
