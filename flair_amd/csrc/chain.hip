@@ -331,8 +331,6 @@ __global__ __launch_bounds__(512, 2) void conv_chain_kernel(ChainArgs a) {
         pbB[ii] = ((q / TW) * WM + (q % TW)) * PITCH;
         wbB[ii] = ((blk * 64 + lr) * 9) * PITCH;
     }
-    constexpr int FP = 32 * 4 + 16;                                // f32 staging pitch of the epilogue (32 couts)
-    constexpr int PPX = 32 / VEC;                                  // 16-byte output pieces per pixel and 32 couts
     for (int batch = 0; batch < nBatch; ++batch) {
         f32x16 acc[MAXIB][2];
 #pragma unroll
@@ -364,71 +362,86 @@ __global__ __launch_bounds__(512, 2) void conv_chain_kernel(ChainArgs a) {
             }
         }
         if (batch == 0) STAMP(4);
-        // ---- epilogue of this batch: per wave, 32 couts at a time through a private f32 tile in sw
-        char* tilebuf = sw + wave * 32 * FP;
+        // ---- epilogue of this batch, straight from the accumulators (no LDS round trip, no barrier).  A lane of
+        // the 32x32 MFMA result holds 4 consecutive couts of its pixel per register quad (quad g: couts 8g + 4*lh ..);
+        // v_permlane32_swap between the two half-waves turns quads 2j, 2j+1 into 8 consecutive couts per lane
+        // (lower half: 16j .. 16j+7, upper half: 16j+8 .. 16j+15), i.e. one 16-byte bf16 store (f32: the quad is
+        // already 16 bytes) and residual loads of the same shape.
 #pragma unroll
         for (int ii = 0; ii < MAXIB; ++ii) {
             const int it = wave + ii * NW;
-            const bool active = it < NITB;
+            if (it >= NITB) continue;                               // wave-uniform: every lane of a wave takes part in the swaps
             const int g = it % NGB, blk = it / NGB;
+            const int q = g * 32 + lr;
+            const int hh = h0 + q / TW, ww = w0 + q % TW;
+            const long p = frameOff + (long)hh * a.W + ww;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                if (active) {
+                const int cofrag = batch * WROWS + blk * 64 + i * 32;
+                if constexpr (sizeof(E) == 4) {
 #pragma unroll
-                    for (int gq = 0; gq < 4; ++gq)
-                        *reinterpret_cast<float4*>(tilebuf + lr * FP + (8 * gq + 4 * lh) * 4) =
-                            make_float4(acc[ii][i][4 * gq], acc[ii][i][4 * gq + 1], acc[ii][i][4 * gq + 2],
-                                        acc[ii][i][4 * gq + 3]);
-                }
-                // the tile is private to this wavefront: LDS operations of one wave complete in order, so only
-                // the compiler has to be kept from reordering the transposed reads above the writes
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                if (active) {
-                    const int cobase = batch * WROWS + blk * 64 + i * 32;
-#pragma unroll
-                    for (int it2 = 0; it2 < 32 * PPX / 64; ++it2) {
-                        const int id = it2 * 64 + lane;
-                        const int px = id / PPX, pc = id % PPX;
-                        const int co = cobase + pc * VEC;
-                        const int q = g * 32 + px;
-                        const int hh = h0 + q / TW, ww = w0 + q % TW;
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const int co = cofrag + 8 * gq + 4 * lh;
+                        float v[4] = {acc[ii][i][4 * gq], acc[ii][i][4 * gq + 1], acc[ii][i][4 * gq + 2], acc[ii][i][4 * gq + 3]};
+                        if (a.actB == FLAIR_ACT_DCN_OFFSETS)
+                            dcn_offset_act<4>(v, co, a.actParam, a.actPeriod);
+                        else
+                            act_vec<4>(v, a.actB);
                         if (co < a.CoutB && hh < a.H) {
-                            const long p = frameOff + (long)hh * a.W + ww;
-                            float v[VEC];
-                            const float* src = reinterpret_cast<const float*>(tilebuf + px * FP) + pc * VEC;
-#pragma unroll
-                            for (int e = 0; e < VEC; e += 4) {
-                                const float4 f = *reinterpret_cast<const float4*>(src + e);
-                                v[e] = f.x; v[e + 1] = f.y; v[e + 2] = f.z; v[e + 3] = f.w;
-                            }
-                            if (a.actB == FLAIR_ACT_DCN_OFFSETS)
-                                dcn_offset_act<VEC>(v, co, a.actParam, a.actPeriod);
-                            else
-                                act_vec<VEC>(v, a.actB);
                             if (a.res0) {
-                                float r[VEC];
+                                float r[4];
                                 Vec16<E>::load(reinterpret_cast<const E*>(a.res0) + p * a.res0Ld + co, r);
 #pragma unroll
-                                for (int e = 0; e < VEC; ++e) v[e] += r[e];
+                                for (int e = 0; e < 4; ++e) v[e] += r[e];
                             }
                             if (a.res1) {
-                                float r[VEC];
+                                float r[4];
                                 Vec16<E>::load(reinterpret_cast<const E*>(a.res1) + p * a.res1Ld + co, r);
 #pragma unroll
-                                for (int e = 0; e < VEC; ++e) v[e] += r[e];
+                                for (int e = 0; e < 4; ++e) v[e] += r[e];
                             }
 #pragma unroll
-                            for (int e = 0; e < VEC; ++e) v[e] *= a.outScale;
+                            for (int e = 0; e < 4; ++e) v[e] *= a.outScale;
+                            Vec16<E>::store(reinterpret_cast<E*>(a.y) + p * a.yLd + co, v);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int co = cofrag + 16 * j + 8 * lh;    // after the swap
+                        float v[8];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const auto sw2 = __builtin_amdgcn_permlane32_swap(
+                                __float_as_uint(acc[ii][i][8 * j + e]), __float_as_uint(acc[ii][i][8 * j + 4 + e]), false, false);
+                            v[e] = __uint_as_float(sw2[0]);
+                            v[4 + e] = __uint_as_float(sw2[1]);
+                        }
+                        if (a.actB == FLAIR_ACT_DCN_OFFSETS)
+                            dcn_offset_act<8>(v, co, a.actParam, a.actPeriod);
+                        else
+                            act_vec<8>(v, a.actB);
+                        if (co < a.CoutB && hh < a.H) {
+                            if (a.res0) {
+                                float r[8];
+                                Vec16<E>::load(reinterpret_cast<const E*>(a.res0) + p * a.res0Ld + co, r);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) v[e] += r[e];
+                            }
+                            if (a.res1) {
+                                float r[8];
+                                Vec16<E>::load(reinterpret_cast<const E*>(a.res1) + p * a.res1Ld + co, r);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) v[e] += r[e];
+                            }
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] *= a.outScale;
                             Vec16<E>::store(reinterpret_cast<E*>(a.y) + p * a.yLd + co, v);
                         }
                     }
                 }
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                __builtin_amdgcn_wave_barrier();
             }
         }
-        __syncthreads();                                           // every wave's tile reads are done: sw may be rewritten
         if (batch == 0) STAMP(5);
         if (batch + 1 < nBatch) {
             write_w();
@@ -444,7 +457,6 @@ int launch_chain(const ChainArgs& a, hipStream_t s) {
     constexpr size_t lds = (size_t)(C / BKE) * (TH + 2) * (TW + 2) * 80 + (size_t)C * 9 * 80 +
                            (HASA ? (size_t)(TH + 4) * (TW + 4) * 80 : 0) + (size_t)(C + CHAIN_MAX_COUTB) * 4;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static_assert((size_t)C * 9 * 80 >= 8 * 32 * (32 * 4 + 16), "epilogue tiles must fit the weight buffer");
     static bool attr = false;
     if (!attr) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_chain_kernel<E, C, TH, TW, HASA>),

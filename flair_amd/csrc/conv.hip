@@ -356,6 +356,79 @@ void conv3x3_halo_kernel(ConvArgs a) {
     }
 
     if (FLAIR_DBG(a) == 5) return;
+    // ---- epilogue, straight from the accumulators.  A lane of the 32x32 MFMA result holds 4 consecutive couts of its
+    // pixel per register quad (quad g: couts 8g + 4*lh ..); v_permlane32_swap between the two half-waves turns quads
+    // 2j, 2j+1 into 8 consecutive couts per lane (lower half 16j .. 16j+7, upper half 16j+8 .. 16j+15): one 16-byte bf16
+    // store and 16-byte residual loads per lane, 32 contiguous bytes per pixel and instruction (f32: a quad already is
+    // 16 bytes).  Measured against the LDS-transposed epilogue below on the clip-level shapes (tools/bench_conv.py, one
+    // box): 117.5 vs 121.6 us (64->64 2-D), 290 vs 268 us (3-D), equal elsewhere -- two workgroups per CU already hide
+    // either epilogue, so the LDS form stays the default and this one is selected with FLAIR_CONV_SWAP_EPILOGUE=1.
+    if ((a.Cout & 7) == 0 && a.debug == 7) {
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) {
+            const int h = h0 + wave * RPW + j, w = w0 + lr;
+            const long p = ((long)t * a.H + h) * a.W + w;
+            const bool rowok = h < a.H;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if constexpr (sizeof(E) == 4) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int co = co0 + i * 32 + 8 * g + 4 * lh;
+                        if (rowok) store_quad<E>(a, p, co, acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2],
+                                                 acc[j][i][4 * g + 3]);
+                    }
+                } else {
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const int co = co0 + i * 32 + 16 * jj + 8 * lh;
+                        float v[8];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const auto sw2 = __builtin_amdgcn_permlane32_swap(
+                                __float_as_uint(acc[j][i][8 * jj + e]), __float_as_uint(acc[j][i][8 * jj + 4 + e]), false, false);
+                            v[e] = __uint_as_float(sw2[0]);
+                            v[4 + e] = __uint_as_float(sw2[1]);
+                        }
+                        if (!rowok || co >= a.Cout) continue;
+                        if (a.bias) {
+                            const float4 b0 = *reinterpret_cast<const float4*>(a.bias + co);
+                            const float4 b1 = *reinterpret_cast<const float4*>(a.bias + co + 4);
+                            v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+                            v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                        }
+                        if (a.fbias) {
+                            const float* fb = a.fbias + (long)t * a.fbiasLd + co;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] += fb[e];
+                        }
+                        if (a.act == FLAIR_ACT_DCN_OFFSETS) {
+                            dcn_offset_act<8>(v, co, a.actParam, a.actPeriod);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], a.act);
+                        }
+                        if (a.res0) {
+                            float r[8];
+                            Vec16<E>::load(reinterpret_cast<const E*>(a.res0) + p * a.res0Ld + co, r);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] += r[e];
+                        }
+                        if (a.res1) {
+                            float r[8];
+                            Vec16<E>::load(reinterpret_cast<const E*>(a.res1) + p * a.res1Ld + co, r);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] += r[e];
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] *= a.outScale;
+                        Vec16<E>::store(reinterpret_cast<E*>(a.y) + p * a.yLd + co, v);
+                    }
+                }
+            }
+        }
+        return;
+    }
     // ---- epilogue.  The accumulator layout gives each lane 4 channels of one pixel (8-byte
     // pieces scattered over 32 pixels per store).  Transpose each wave's 32 x 64 tile through LDS
     // (staged as f32, so bias / activation / residuals stay exact) and let consecutive lanes
@@ -1097,7 +1170,10 @@ extern "C" int flair_conv_nhwc(const flair_conv_params* p, const void* const* x,
     FLAIR_CHECK(a.stride == 1 || a.stride == 2, "flair_conv_nhwc: stride %d unsupported", p->stride);
     a.part = nullptr;
     a.splitK = 1;
-    a.debug = 0;
+    {   // A/B switch: 7 selects the register-transposed (v_permlane32_swap) epilogue of the throughput halo kernel
+        static const int swapEpilogue = getenv("FLAIR_CONV_SWAP_EPILOGUE") ? atoi(getenv("FLAIR_CONV_SWAP_EPILOGUE")) : 0;
+        a.debug = swapEpilogue ? 7 : 0;
+    }
 #ifdef FLAIR_TIMING_SWITCHES
     {
         static const int dbg = getenv("FLAIR_CONV_DEBUG") ? atoi(getenv("FLAIR_CONV_DEBUG")) : 0;
