@@ -74,9 +74,11 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--task", default="gaussian", choices=["gaussian", "jpeg", "x8_bicubic", "x16_bicubic"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay a captured hipGraph of the UNet forward instead of launching eagerly "
-                         "(measured: no gain, the step is GPU-bound; profiles/README.md)")
+    ap.add_argument("--graph", dest="graph", action="store_true", default=True,
+                    help="replay a captured hipGraph of the UNet forward (default): bit-identical to eager launches and "
+                         "as fast on one GPU (the step is GPU-bound), but the host spends ~5 ms instead of ~60 ms per "
+                         "step, which keeps 8 rank processes on one node from competing for CPU time")
+    ap.add_argument("--no-graph", dest="graph", action="store_false", help="launch every kernel eagerly")
     return ap.parse_args()
 
 
