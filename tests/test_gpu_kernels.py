@@ -149,6 +149,11 @@ def test_conv_cases_cover_every_kernel_variant():
     (4, 8, 8, 96, 0, True, 0, 1),
     (16, 4, 4, 1024, 0, True, 0, None),
     (3, 4, 4, 1024, 1024, True, 0, None),          # 2048 channels: more 16-byte slots than 256 threads in f32
+    # one-launch small-tensor kernel (a workgroup per group, <= 128 KB per group; the first case is just above): two segments, per-frame stats
+    (16, 32, 32, 256, 0, True, 0, None),
+    (16, 16, 16, 256, 256, True, 0, None),
+    (4, 8, 8, 256, 0, True, 0, 1),
+    (8, 16, 16, 512, 0, False, 0, None),
 ])
 def test_group_norm(dev, dtype, case):
     ops = _ops()
@@ -158,7 +163,7 @@ def test_group_norm(dev, dtype, case):
     x = rb(torch.randn(T, C, H, W, generator=g) * 1.7 + 0.3, dtype)
     gamma = torch.randn(C, generator=g)
     beta = torch.randn(C, generator=g)
-    emb = torch.randn(T, 2 * C + 5, generator=g) * 0.5 if film else None
+    emb = torch.randn(T, 2 * C + (5 if C < 512 else 8), generator=g) * 0.5 if film else None   # rows (un)aligned to 16 B
     if fps == 1:
         n = F.group_norm(x, 32, gamma, beta, 1e-5)
     else:
