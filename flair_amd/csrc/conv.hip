@@ -1028,13 +1028,15 @@ int launch(const ConvArgs& a0, hipStream_t s) {
 // Split-K factor for the im2col path: deep-K convolutions on few pixels (the 16x16 .. 4x4
 // levels: K up to 13,824, <= 256 tiles) would otherwise run one long serial K loop per CU.
 int choose_split(const ConvArgs& a, int variant) {
-    if (variant != 2) return 1;
+    if (variant > 2) return 1;
+    const int maxBlocks = variant == 0 ? 512 : 1024, maxSplit = 16;
+    const int tc = variant == 0 ? 128 : 64, tp = variant == 2 ? 64 : 128;
     const int bke = 64 / (a.wBytes && a.CinTot ? (int)(a.wBytes / ((unsigned long long)a.Cout * a.KT * a.KH * a.KW * a.CinTot)) : 2);
     const long nk = (long)a.KT * a.KH * a.KW * (a.CinTot / bke);
-    const long tiles = (long)cdiv(a.P, 64) * cdiv(a.Cout, 64);
+    const long tiles = (long)cdiv(a.P, tp) * cdiv(a.Cout, tc);
     if (tiles >= 384 || nk < 32) return 1;
-    long s = 1024 / tiles;
-    if (s > 16) s = 16;
+    long s = maxBlocks / tiles;
+    if (s > maxSplit) s = maxSplit;
     if (s > nk / 8) s = nk / 8;
     return s < 1 ? 1 : (int)s;
 }
@@ -1054,6 +1056,11 @@ int choose_variant(const ConvArgs& a) {
     }
     const long tiles128 = (long)cdiv(a.P, 128) * cdiv(a.Cout, 128);
     if (a.Cout > 64 && tiles128 >= 512) return 0;
+    // deep-K convolutions on few pixels (16x16 / 8x8 levels, K = 2304 .. 13,824): 128x128 tiles with split-K move half
+    // the L2->LDS bytes of 64x64 tiles per flop; hipGraph-timed 256->256 3x3x3 at 16x16^2: 57.7 -> 43.4 us,
+    // 512->512 at 16x8^2: 58.1 -> 45.2 us (4x4 stays on 64x64: 29.6 vs 34.0 us).  FLAIR_DEEPK_TILE128=0: round-1 choice.
+    static const bool deepk128 = !(getenv("FLAIR_DEEPK_TILE128") && atoi(getenv("FLAIR_DEEPK_TILE128")) == 0);
+    if (deepk128 && a.Cout >= 128 && a.P >= 1024 && tiles128 <= 64 && (long)a.KT * a.KH * a.KW * a.CinTot >= 2304) return 0;
     const long tiles64x128 = (long)cdiv(a.P, 128) * cdiv(a.Cout, 64);
     if (tiles64x128 >= 512) return 1;
     return 2;

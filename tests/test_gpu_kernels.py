@@ -45,6 +45,9 @@ def _ops():
     (4, 64, 64, [64], 128, (3, 3, 3), 0, 1),
     (1, 250, 256, [64], 64, (1, 3, 3), 3, 1),       # last row of tiles hangs over the image
     (1, 125, 128, [32], 128, (1, 3, 3), 0, 0),
+    # deep-K convolutions on few pixels: 128 x 128 tiles with split-K (16x16 / 8x8 levels)
+    (8, 16, 16, [256], 256, (3, 3, 3), 3, 1),
+    (16, 8, 8, [256, 256], 384, (1, 3, 3), 0, 2),
 ])
 def test_conv(dev, dtype, case):
     ops = _ops()
