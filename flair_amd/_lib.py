@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libflair_hip.so")
 
 FLAIR_F32, FLAIR_BF16 = 0, 1
-ACT_NONE, ACT_RELU, ACT_LRELU01, ACT_SILU, ACT_DCN_OFFSETS = 0, 1, 2, 3, 4
+ACT_NONE, ACT_RELU, ACT_LRELU01, ACT_SILU, ACT_DCN_OFFSETS, ACT_LRELU02, ACT_GELU = 0, 1, 2, 3, 4, 5, 6
 
 
 class FlairHipUnavailable(RuntimeError):
@@ -31,7 +31,7 @@ class ConvParams(ctypes.Structure):
                 ("seg_c", ctypes.c_int * 4), ("seg_ld", ctypes.c_int * 4),
                 ("y_ld", ctypes.c_int), ("res_ld", ctypes.c_int * 2), ("act", ctypes.c_int),
                 ("out_scale", ctypes.c_float), ("frame_bias_ld", ctypes.c_int), ("stride", ctypes.c_int),
-                ("act_param", ctypes.c_float), ("act_period", ctypes.c_int)]
+                ("act_param", ctypes.c_float), ("act_period", ctypes.c_int), ("asym_pad", ctypes.c_int)]
 
 
 _lib = None

@@ -14,4 +14,4 @@ void flair_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* flair_last_error(void) { return g_err; }
-extern "C" int flair_abi_version(void) { return 2; }
+extern "C" int flair_abi_version(void) { return 3; }

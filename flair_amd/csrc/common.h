@@ -94,6 +94,8 @@ __device__ __forceinline__ float apply_act(float v, int act) {
         case FLAIR_ACT_RELU: return v > 0.f ? v : 0.f;
         case FLAIR_ACT_LRELU01: return v > 0.f ? v : 0.1f * v;
         case FLAIR_ACT_SILU: return silu_f(v);
+        case FLAIR_ACT_LRELU02: return v > 0.f ? v : 0.2f * v;
+        case FLAIR_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
         default: return v;
     }
 }

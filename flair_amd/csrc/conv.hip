@@ -53,6 +53,7 @@ struct ConvArgs {
     int fbiasLd;
     int debug;             // phase-timing switches, compiled in only with -DFLAIR_TIMING_SWITCHES (see FLAIR_DBG)
     int stride;            // spatial stride (1 or 2; im2col path only)
+    int tapShift;          // asym_pad: K/2 added to every spatial tap offset (taps start at stride*i)
     float actParam;        // FLAIR_ACT_DCN_OFFSETS: max residue magnitude
     int actPeriod;         // FLAIR_ACT_DCN_OFFSETS: 3 * deform groups
     int Hin, Win;          // input frame size (== H, W when stride == 1); H, W, P describe the OUTPUT
@@ -868,7 +869,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         const int coff = cb * BKE + chunk * VEC;
 #pragma unroll
         for (int i = 0; i < XR; ++i) {
-            const int t2 = xt[i] + dt, h2 = xh[i] * a.stride + dh, w2 = xw[i] * a.stride + dw;
+            const int t2 = xt[i] + dt, h2 = xh[i] * a.stride + dh + a.tapShift, w2 = xw[i] * a.stride + dw + a.tapShift;
             const bool ok = xvalid[i] && (unsigned)t2 < (unsigned)a.T && (unsigned)h2 < (unsigned)a.Hin &&
                             (unsigned)w2 < (unsigned)a.Win;
             const unsigned off = ok ? (unsigned)((((t2 - fb) * a.Hin + h2) * a.Win + w2) * ld + coff) * ESZ : FLAIR_OOB;
@@ -1175,6 +1176,9 @@ extern "C" int flair_conv_nhwc(const flair_conv_params* p, const void* const* x,
         a.KT = g.KT; a.KH = g.KH; a.KW = g.KW; a.Cout = g.Cout;
     }
     FLAIR_CHECK(a.stride == 1 || a.stride == 2, "flair_conv_nhwc: stride %d unsupported", p->stride);
+    FLAIR_CHECK(!p->asym_pad || (a.stride == 2 && a.KH == a.KW && a.KT == 1 && p->H % 2 == 0 && p->W % 2 == 0),
+                "flair_conv_nhwc: asym_pad needs a square 2-D stride-2 kernel on even frames");
+    a.tapShift = p->asym_pad ? a.KH / 2 : 0;
     a.part = nullptr;
     a.splitK = 1;
     {   // A/B switch: 7 selects the register-transposed (v_permlane32_swap) epilogue of the throughput halo kernel

@@ -10,13 +10,13 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import (ACT_DCN_OFFSETS, ACT_LRELU01, ACT_NONE, ACT_RELU, ACT_SILU, ConvParams, check, dtype_code, lib,
+from ._lib import (ACT_DCN_OFFSETS, ACT_GELU, ACT_LRELU01, ACT_LRELU02, ACT_NONE, ACT_RELU, ACT_SILU, ConvParams, check, dtype_code, lib,
                    ptr, stream)
 
 __all__ = ["conv", "conv_chain", "group_norm", "nchw_to_clip", "clip_to_nchw", "timestep_embedding", "linear",
            "qkv_attention", "temporal_attention", "flow_warp", "flow_compose", "resize",
            "dcn_align", "dcn_raw_permutation", "scale_pixels", "predict_xstart", "sampler_update",
-           "ACT_NONE", "ACT_RELU", "ACT_LRELU01", "ACT_SILU", "ACT_DCN_OFFSETS"]
+           "ACT_NONE", "ACT_RELU", "ACT_LRELU01", "ACT_SILU", "ACT_DCN_OFFSETS", "ACT_LRELU02", "ACT_GELU"]
 
 
 class GnParams(ctypes.Structure):
@@ -87,7 +87,7 @@ def pad_channels(c, dtype):
 
 # --------------------------------------------------------------------------- conv
 def conv(xs, weight, bias, cout, kernel, *, out=None, act=ACT_NONE, res0=None, res1=None,
-         out_scale=1.0, stride=1, frame_bias=None, act_param=0.0, act_period=0):
+         out_scale=1.0, stride=1, frame_bias=None, act_param=0.0, act_period=0, asym_pad=False):
     """Y = act(conv(cat(xs), W) + bias) + res0 + res1, times out_scale.
 
     xs: one clip tensor or a list of up to 4 (channel-concatenated implicitly; each
@@ -111,6 +111,7 @@ def conv(xs, weight, bias, cout, kernel, *, out=None, act=ACT_NONE, res0=None, r
         p.seg_ld[i] = _ld(x)
         arr[i] = x.data_ptr()
     p.stride = stride
+    p.asym_pad = int(asym_pad)
     p.frame_bias_ld = frame_bias.stride(0) if frame_bias is not None else 0
     if frame_bias is not None:
         assert frame_bias.dtype == torch.float32 and frame_bias.stride(1) == 1 and frame_bias.shape[0] == T
@@ -662,4 +663,75 @@ def gated_blend(x, m, gate, out=None):
         out = torch.empty_like(x)
     check(lib().flair_gated_blend(ptr(x), _ld(x), ptr(m), _ld(m), ptr(gate), gate.stride(0), dtype_code(x), C, T,
                                   ctypes.c_long(H * W), ptr(out), _ld(out), stream()), "flair_gated_blend")
+    return out
+
+
+# --------------------------------------------------------------------------- CodeFormer prior pieces
+def layer_norm(x, gamma, beta, *, eps=1e-5, pos=None, out=None, out_pos=None):
+    """nn.LayerNorm over the channels of every pixel of a clip tensor.  With ``pos`` ((rows_per_frame, C) f32)
+    also returns y + pos (broadcast over frames): -> y or (y, y_pos)."""
+    F_, H, W, C = x.shape
+    if out is None:
+        out = torch.empty((F_, H, W, C), dtype=x.dtype, device=x.device)
+    if pos is not None and out_pos is None:
+        out_pos = torch.empty((F_, H, W, C), dtype=x.dtype, device=x.device)
+    if pos is not None:
+        assert pos.dtype == torch.float32 and pos.is_contiguous() and pos.shape == (H * W, C)
+    check(lib().flair_layernorm_nhwc(ptr(x), dtype_code(x), _ld(x), ctypes.c_long(F_ * H * W), C, ptr(_f32(gamma)),
+                                     ptr(_f32(beta)), ctypes.c_float(eps), ptr(out), _ld(out), ptr(pos),
+                                     H * W if pos is not None else 0, ptr(out_pos), _ld(out_pos) if pos is not None else 0,
+                                     stream()), "flair_layernorm_nhwc")
+    return out if pos is None else (out, out_pos)
+
+
+def attention_wide(qkv, heads, head_dim, *, q_off, k_off, v_off, head_stride, out=None):
+    """Attention over the H*W pixels of each frame with heads of any width (flair_attention_wide)."""
+    F_, H, W, _ = qkv.shape
+    p = AttnParams()
+    p.dtype = dtype_code(qkv)
+    p.frames, p.L, p.heads, p.head_dim = F_, H * W, heads, head_dim
+    p.ld = _ld(qkv)
+    if out is None:
+        out = torch.empty((F_, H, W, heads * head_dim), dtype=qkv.dtype, device=qkv.device)
+    p.out_ld = _ld(out)
+    p.q_off, p.k_off, p.v_off, p.head_stride = q_off, k_off, v_off, head_stride
+    p.scale = 1.0 / (head_dim ** 0.5)
+    check(lib().flair_attention_wide(ctypes.byref(p), ptr(qkv), ptr(out), stream()), "flair_attention_wide")
+    return out
+
+
+def argmax_codebook(logits, n_codes, codebook, *, forced_idx=None, out=None):
+    """logits: (F,H,W,>=n_codes) clip tensor; codebook (n_codes, D) f32 -> (codes (F,H,W,D), idx (F*H*W,) int32)."""
+    F_, H, W, _ = logits.shape
+    D = codebook.shape[1]
+    assert codebook.dtype == torch.float32 and codebook.is_contiguous() and codebook.shape[0] == n_codes
+    if out is None:
+        out = torch.empty((F_, H, W, D), dtype=logits.dtype, device=logits.device)
+    idx = torch.empty((F_ * H * W,), dtype=torch.int32, device=logits.device)
+    if forced_idx is not None:
+        assert forced_idx.dtype == torch.int32 and forced_idx.is_contiguous() and forced_idx.numel() == idx.numel()
+    check(lib().flair_argmax_codebook(ptr(logits), dtype_code(logits), _ld(logits), ctypes.c_long(F_ * H * W), n_codes,
+                                      ptr(codebook), D, ptr(forced_idx), ptr(idx), ptr(out), _ld(out), stream()),
+          "flair_argmax_codebook")
+    return out, idx
+
+
+def adain(content, style, *, eps=1e-5, out=None):
+    F_, H, W, C = content.shape
+    assert style.shape == content.shape and style.dtype == content.dtype
+    if out is None:
+        out = torch.empty((F_, H, W, C), dtype=content.dtype, device=content.device)
+    check(lib().flair_adain_nhwc(ptr(content), _ld(content), ptr(style), _ld(style), dtype_code(content), F_, H * W, C,
+                                 ctypes.c_float(eps), ptr(out), _ld(out), stream()), "flair_adain_nhwc")
+    return out
+
+
+def sft_fuse(dec, scale, shift, w, out=None):
+    """dec + w * (dec * scale + shift) on dense clip tensors."""
+    assert dec.is_contiguous() and scale.is_contiguous() and shift.is_contiguous()
+    assert dec.shape == scale.shape == shift.shape and dec.dtype == scale.dtype == shift.dtype
+    if out is None:
+        out = torch.empty_like(dec)
+    check(lib().flair_sft_fuse(ptr(dec), ptr(scale), ptr(shift), ctypes.c_float(w), dtype_code(dec),
+                               ctypes.c_long(dec.numel()), ptr(out), stream()), "flair_sft_fuse")
     return out

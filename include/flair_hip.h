@@ -51,7 +51,9 @@ typedef enum {
      * channel co -> act_param * tanh(v) if co % period < 2*period/3 (the (dy,dx) residues, act_param =
      * max_residue_magnitude), else sigmoid(v) (the modulation mask).  flair_dcn_align then takes the
      * finished values (raw_activated = 1) instead of re-deriving them per gathered channel group. */
-    FLAIR_ACT_DCN_OFFSETS = 4
+    FLAIR_ACT_DCN_OFFSETS = 4,
+    FLAIR_ACT_LRELU02 = 5, /* LeakyReLU(0.2): SFT scale / shift branches, codeformer.py:579-588 */
+    FLAIR_ACT_GELU = 6     /* exact (erf) GELU: transformer MLP, codeformer.py:520-528 */
 } flair_act;
 
 /* Last error message of the calling thread ("" if none). */
@@ -95,6 +97,9 @@ typedef struct {
                  * ceil(H/stride) x ceil(W/stride) (PyTorch Conv2d(k, stride, padding=k//2)) */
     float act_param; /* FLAIR_ACT_DCN_OFFSETS: max_residue_magnitude */
     int act_period;  /* FLAIR_ACT_DCN_OFFSETS: 3 * deform_groups (multiple of 24) */
+    int asym_pad;    /* 1 (stride 2 only): taps at stride*i .. stride*i + K-1, zeros past the bottom / right edge =
+                      * F.pad(x, (0, 1, 0, 1)) + Conv2d(k, stride 2, padding 0), CodeFormer's Downsample
+                      * (codeformer.py:138-149); 0: taps centred (padding k//2) */
 } flair_conv_params;
 
 size_t flair_conv_workspace_bytes(const flair_conv_params* p);
@@ -357,6 +362,32 @@ int flair_matmul_f32(const float* A, long a_batch_stride, const float* B, long b
  * y[o][i][n] = sum_k w[k][i] * x[o][fov[k][i]][n]; fov int32 [taps][Lout], w f32 [taps][Lout]. */
 int flair_gather_mac_f32(const float* x, long outer, int Lin, long inner, const int* fov,
                          const float* w, int taps, int Lout, float* y, hipStream_t stream);
+
+/* ------------------------------------------------------------- CodeFormer auxiliary prior
+ * (guided_diffusion/codeformer.py, called from gaussian_diffusion.py:471-496 as
+ * aux_model(pred_xstart, t, x)).  Its convolutions, GroupNorms, 1x1 projections and 8 x 64 multi-head attention
+ * run on the entry points above; these are the pieces only the prior needs. */
+/* nn.LayerNorm(C) over the channels of each of `rows` pixels (codeformer.py:541-542, :639), eps inside the
+ * square root.  Optional second output y2 = y + pos[row % pos_rows][C] (q = k = norm(x) + pos, :561-562). */
+int flair_layernorm_nhwc(const void* x, int dtype, int x_ld, long rows, int C, const float* gamma,
+                         const float* beta, float eps, void* y, int y_ld, const float* pos, int pos_rows,
+                         void* y2, int y2_ld, hipStream_t stream);
+/* Attention with heads of any width (AttnBlock.forward, codeformer.py:217-241: one head of C = 512 over the 256
+ * pixels of the 16x16 level).  Same layout contract as flair_qkv_attention; head_dim a multiple of 8 (bf16) / 4
+ * (f32), 64 * (head_dim + L) bytes of LDS <= 128 KiB. */
+int flair_attention_wide(const flair_attn_params* p, const void* qkv, void* out, hipStream_t stream);
+/* idx[row] = argmax_n logits[row][n] (softmax + topk(1) of codeformer.py:727-728; first index on ties) and
+ * y[row][0..D) = codebook[idx[row]] (VectorQuantizer.get_codebook_feat, :82-94).  codebook: [N][D] f32.
+ * forced_idx (or NULL): use these indices instead of the arg-max (tests).  idx may be NULL. */
+int flair_argmax_codebook(const void* logits, int dtype, int ld, long rows, int N, const float* codebook, int D,
+                          const int* forced_idx, int* idx, void* y, int y_ld, hipStream_t stream);
+/* adaptive_instance_normalization(content, style) of codeformer.py:437-470 on [frames][HW][C] tensors:
+ * per (frame, channel) mean and sqrt(unbiased variance + eps) of both, y = (content - mc) / sc * ss + ms. */
+int flair_adain_nhwc(const void* content, int c_ld, const void* style, int s_ld, int dtype, int frames, int HW,
+                     int C, float eps, void* y, int y_ld, hipStream_t stream);
+/* Fuse_sft_block tail (codeformer.py:595-596): y = dec + w * (dec * scale + shift) over n dense elements. */
+int flair_sft_fuse(const void* dec, const void* scale, const void* shift, float w, int dtype, long n, void* y,
+                   hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -169,7 +169,32 @@ def g5_unet_64():
          **{"stage_" + k.replace(".", "_"): v.half() for k, v in stages.items()})
 
 
-EXTRA = {"g4": g4_blocks, "g8": g8_blur_forward, "g5_64": g5_unet_64}
+def codeformer_input(batch=1, seed=9):
+    """A smooth face-sized field in [-1, 1] plus pixel noise (shared with tests/test_codeformer.py)."""
+    gen = torch.Generator().manual_seed(seed)
+    low = torch.randn(batch, 3, 32, 32, generator=gen)
+    x = torch.nn.functional.interpolate(low, size=(512, 512), mode="bicubic", align_corners=False) * 0.6
+    return h16((x + 0.05 * torch.randn(batch, 3, 512, 512, generator=gen)).clamp(-1, 1))
+
+
+def g9_codeformer():
+    """G9: the reference's CodeFormer, built as scripts/video_sample.py:351-357 builds it,
+    name-seeded weights, called as the sampler's aux_model calls it (``gan(x0, w=1.0, adain=True)``,
+    video_sample.py:450-452) plus the w = 0 / no-AdaIN variant on a pixel subset."""
+    import refimport
+    cf = refimport.ref("codeformer")
+    gan = cf.CodeFormer(dim_embd=512, codebook_size=1024, n_head=8, n_layers=9, connect_list=["32", "64", "128", "256"])
+    name_seeded_weights(gan)
+    gan.eval()
+    x = codeformer_input()
+    out, logits, lq = gan(x, w=1.0, adain=True)
+    out0 = gan(x, w=0, adain=False)[0]
+    sd = gan.state_dict()
+    save("g9_codeformer", x=x.half(), out=out, logits=logits, lq_feat=lq, out_w0_sub=out0[..., ::4, ::4],
+         param_names=np.array(list(sd.keys())), param_shapes=np.array([";".join(map(str, v.shape)) for v in sd.values()]))
+
+
+EXTRA = {"g4": g4_blocks, "g8": g8_blur_forward, "g5_64": g5_unet_64, "g9": g9_codeformer}
 
 
 def main():
