@@ -73,6 +73,11 @@ def parse():
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--task", default="gaussian", choices=["gaussian", "jpeg", "x8_bicubic", "x16_bicubic"])
+    ap.add_argument("--aux", default="identity", choices=["identity", "codeformer"],
+                    help="auxiliary prior inside the step: identity (BASELINE configs; the reference's demos at 256^2 "
+                         "cannot run CodeFormer, which is fixed to 512^2) or the HIP CodeFormer (needs --size 512)")
+    ap.add_argument("--aux-dtype", default="f32", choices=["f32", "bf16"],
+                    help="CodeFormer arithmetic: the reference keeps the prior in fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", dest="graph", action="store_true", default=True,
                     help="replay a captured hipGraph of the UNet forward (default): bit-identical to eager launches and "
@@ -238,11 +243,23 @@ def main():
     else:
         kwargs = dict(low_res_input=init, num_frames=T, enable_cross_frames=True, vsrpp_weights=1.0, rnn_input=rnn)
 
+    aux_model = wl.identity_aux
+    if a.aux == "codeformer":
+        if S != 512:
+            raise SystemExit("--aux codeformer needs --size 512 (codeformer.py:730 reshapes to a 16x16 code grid)")
+        from flair_amd.guided_diffusion.codeformer import CodeFormer
+        torch.manual_seed(1)
+        gan = CodeFormer(dim_embd=512, codebook_size=1024, n_head=8, n_layers=9,
+                         connect_list=["32", "64", "128", "256"]).to(dev).eval()
+        if a.aux_dtype == "bf16":
+            gan.convert_to_bf16()
+        aux_model = wl.codeformer_aux(gan)
+
     W = max(0, a.warmup)
     K = max(1, min(a.steps, TOTAL_STEPS - W - 1))      # keep one step for the instrumented pass
     gen = diffusion.p_sample_loop_progressive(
         model, x_T.shape, noise=x_T, clip_denoised=True, model_kwargs=kwargs, device=dev,
-        restore_fn=restore_fn, aux_model=wl.identity_aux, w=hp["w"], tau=5, aligned=True, rho=hp["rho"],
+        restore_fn=restore_fn, aux_model=aux_model, w=hp["w"], tau=5, aligned=True, rho=hp["rho"],
         noise_level=hp["noise_level"], zeta=hp["zeta"])
 
     def sync():
@@ -340,7 +357,8 @@ def main():
                                + ", one clip per GPU",
                    "steps_per_clip": TOTAL_STEPS, "value_definition": f"n_gpus*frames/({TOTAL_STEPS}*mean timed step)",
                    "finite_output": finite, "weight_broadcast_s": t_bcast, "weight_broadcast_bytes": bcast_bytes,
-                   "hip_graph": use_graph},
+                   "hip_graph": use_graph,
+                   "aux_prior": "identity" if a.aux == "identity" else f"CodeFormer (HIP, {a.aux_dtype}) every step t >= tau"},
         "roofline": {"bound": "mfma", "kernel": CONV_VARIANTS.get(key[0][1], str(key[0][1])) + " " + key[1],
                      "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                      "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",

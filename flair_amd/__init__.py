@@ -19,11 +19,10 @@ def install_as_guided_diffusion(reference_root=None):
     ``flair_amd/guided_diffusion`` first and -- when ``reference_root`` (a checkout of
     wustl-cig/FLAIR) is given -- the reference's own ``guided_diffusion`` directory second.
     Every module this package implements (gaussian_diffusion, respace, unet_new, unet, sr3,
-    nn, nn_new, script_util, pseudoSR, jpeg, restore_util, resizer, ...) is imported under its
-    real name and aliased, so its relative imports keep working; everything else the script
-    imports (``guided_diffusion.codeformer``, ``guided_diffusion.facelib...``,
-    scripts/video_sample.py:17,28) still resolves to the reference's files through the second
-    path entry.  Returns the package object."""
+    nn, nn_new, script_util, pseudoSR, jpeg, restore_util, resizer, codeformer, ...) is imported
+    under its real name and aliased, so its relative imports keep working; everything else the
+    script imports (``guided_diffusion.facelib...``, scripts/video_sample.py:28) still resolves to
+    the reference's files through the second path entry.  Returns the package object."""
     import importlib
     import pkgutil
     import types

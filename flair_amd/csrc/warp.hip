@@ -213,6 +213,24 @@ __global__ void vsrpp_warp2_kernel(const E* prop, int propLd, const E* feat2, in
 __device__ __forceinline__ float cubic1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
 __device__ __forceinline__ float cubic2(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
 
+// nearest x2 (F.interpolate(scale_factor=2) of Upsample layers): a pure copy, 16 bytes per thread
+template <typename E>
+__global__ void nearest2x_kernel(const E* x, int xLd, long F, int Hi, int Wi, int C, E* y, int yLd) {
+    constexpr int VEC = ET<E>::VEC;
+    const int cv = C / VEC;
+    const int Ho = 2 * Hi, Wo = 2 * Wi;
+    const long total = F * Ho * Wo * cv;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * VEC;
+        const long p = i / cv;
+        const int wo = (int)(p % Wo);
+        const int ho = (int)((p / Wo) % Ho);
+        const long f = p / ((long)Wo * Ho);
+        *reinterpret_cast<uint4*>(y + p * yLd + c) =
+            *reinterpret_cast<const uint4*>(x + ((f * Hi + (ho >> 1)) * Wi + (wo >> 1)) * xLd + c);
+    }
+}
+
 // mode: 0 bilinear align_corners=False, 1 bilinear align_corners=True, 2 bicubic
 // (align_corners=False, A=-0.75, border-clamped taps), 3 2x2 average pool, 4 nearest.
 template <typename E>
@@ -323,6 +341,20 @@ extern "C" int flair_resize_nhwc(const void* x, int dtype, int x_ld, int F, int 
                 "flair_resize_nhwc: bad argument");
     FLAIR_CHECK(mode != 3 || (Hi == 2 * Ho && Wi == 2 * Wo), "flair_resize_nhwc: avg-pool needs exact 2x");
     const long n = (long)F * Ho * Wo * C;
+    {
+        const int vec = dtype == FLAIR_BF16 ? 8 : 4;
+        if (mode == 4 && Ho == 2 * Hi && Wo == 2 * Wi && C % vec == 0 && x_ld % vec == 0 && y_ld % vec == 0 &&
+            scale_c0 == 1.f && scale_c1 == 1.f && (dtype == FLAIR_BF16 || dtype == FLAIR_F32)) {
+            if (dtype == FLAIR_BF16)
+                hipLaunchKernelGGL(nearest2x_kernel<bf16_t>, dim3(grid_for(n / vec)), dim3(256), 0, stream, (const bf16_t*)x,
+                                   x_ld, (long)F, Hi, Wi, C, (bf16_t*)y, y_ld);
+            else
+                hipLaunchKernelGGL(nearest2x_kernel<float>, dim3(grid_for(n / vec)), dim3(256), 0, stream, (const float*)x,
+                                   x_ld, (long)F, Hi, Wi, C, (float*)y, y_ld);
+            FLAIR_LAUNCH_CHECK();
+            return FLAIR_OK;
+        }
+    }
     if (dtype == FLAIR_BF16)
         hipLaunchKernelGGL(resize_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, stream, (const bf16_t*)x, x_ld, F,
                            Hi, Wi, C, mode, Ho, Wo, (bf16_t*)y, y_ld, scale_c0, scale_c1);

@@ -69,6 +69,14 @@ def identity_aux(x0, t, xt):
     return x0
 
 
+def codeformer_aux(gan):
+    """The reference's ``aux_model`` closure (scripts/video_sample.py:450-452) around a CodeFormer prior: the
+    sampler hands it pred_xstart of aligned 512x512 faces and blends its first output back in."""
+    def aux_model(x0, *args, **kwargs):
+        return gan(x0, w=1.0, adain=True)[0]
+    return aux_model
+
+
 # ------------------------------------------------------------------ bicubic tasks (sr3.UNet)
 def sr3_config(image_size, use_fp16=True):
     """MODEL_CONFIG['x8_bicubic'] of scripts/video_sample.py:78-96 at clip side `image_size`

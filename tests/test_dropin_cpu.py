@@ -1,7 +1,7 @@
 """The package-level drop-in: after ``flair_amd.install_as_guided_diffusion()`` the import lines of
-the reference's ``scripts/video_sample.py`` (:11-15,27) bind to this package, and names this
-package does not implement (``guided_diffusion.codeformer``, ``guided_diffusion.facelib``, :17,28)
-still resolve to the reference's files when its checkout is supplied."""
+the reference's ``scripts/video_sample.py`` (:11-17,27) bind to this package -- including the CodeFormer
+prior (:17) -- and names this package does not implement (``guided_diffusion.facelib``, :28; training-side
+modules such as ``guided_diffusion.losses``) still resolve to the reference's files when its checkout is supplied."""
 import os
 import subprocess
 import sys
@@ -21,6 +21,7 @@ from guided_diffusion.unet_new import UNetModel as BlurUNet
 import guided_diffusion.pseudoSR as pseudo_sr
 from guided_diffusion.restore_util import SRConv
 from guided_diffusion.jpeg import jpeg_decode, jpeg_encode
+from guided_diffusion.codeformer import CodeFormer
 """
 
 
@@ -42,7 +43,7 @@ def test_script_imports_bind_to_flair_amd():
         from guided_diffusion.nn_new import checkpoint, conv_nd, linear, avg_pool_nd, zero_module, normalization, timestep_embedding
         from guided_diffusion.script_util import create_model_and_diffusion, model_and_diffusion_defaults, add_dict_to_argparser, args_to_dict, str2bool
         import guided_diffusion
-        for cls in (BicubicUNet, BlurUNet, SRConv, SpacedDiffusion):
+        for cls in (BicubicUNet, BlurUNet, SRConv, SpacedDiffusion, CodeFormer):
             assert cls.__module__.startswith("flair_amd.guided_diffusion."), cls.__module__
         assert guided_diffusion.sr3.UNet is BicubicUNet
         d = SpacedDiffusion(use_timesteps=space_timesteps(1000, "100", "uniform"),
@@ -65,10 +66,9 @@ def test_reference_only_modules_stay_importable():
         import flair_amd
         flair_amd.install_as_guided_diffusion({REFERENCE!r})
         {SCRIPT_IMPORTS.replace(chr(10), chr(10) + '        ')}
-        from guided_diffusion.codeformer import CodeFormer            # video_sample.py:17
-        assert CodeFormer.__module__ == "guided_diffusion.codeformer"
-        import guided_diffusion.codeformer as cf
-        assert cf.__file__.startswith({REFERENCE!r}), cf.__file__
+        import guided_diffusion.losses as ls                           # not implemented here: the reference's file
+        assert ls.__file__.startswith({REFERENCE!r}), ls.__file__
+        assert CodeFormer.__module__ == "flair_amd.guided_diffusion.codeformer"       # video_sample.py:17
         spec = importlib.util.find_spec("guided_diffusion.facelib")    # video_sample.py:28 (needs cv2 to import)
         assert spec is not None and any(p.startswith({REFERENCE!r}) for p in spec.submodule_search_locations)
         assert BlurUNet.__module__ == "flair_amd.guided_diffusion.unet_new"
