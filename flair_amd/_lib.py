@@ -31,7 +31,8 @@ class ConvParams(ctypes.Structure):
                 ("seg_c", ctypes.c_int * 4), ("seg_ld", ctypes.c_int * 4),
                 ("y_ld", ctypes.c_int), ("res_ld", ctypes.c_int * 2), ("act", ctypes.c_int),
                 ("out_scale", ctypes.c_float), ("frame_bias_ld", ctypes.c_int), ("stride", ctypes.c_int),
-                ("act_param", ctypes.c_float), ("act_period", ctypes.c_int), ("asym_pad", ctypes.c_int)]
+                ("act_param", ctypes.c_float), ("act_period", ctypes.c_int), ("asym_pad", ctypes.c_int),
+                ("reflect_pad", ctypes.c_int)]
 
 
 _lib = None

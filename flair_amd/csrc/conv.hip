@@ -54,6 +54,7 @@ struct ConvArgs {
     int debug;             // phase-timing switches, compiled in only with -DFLAIR_TIMING_SWITCHES (see FLAIR_DBG)
     int stride;            // spatial stride (1 or 2; im2col path only)
     int tapShift;          // asym_pad: K/2 added to every spatial tap offset (taps start at stride*i)
+    int reflect;           // reflect_pad: out-of-frame taps read the mirrored pixel (im2col path)
     float actParam;        // FLAIR_ACT_DCN_OFFSETS: max residue magnitude
     int actPeriod;         // FLAIR_ACT_DCN_OFFSETS: 3 * deform groups
     int Hin, Win;          // input frame size (== H, W when stride == 1); H, W, P describe the OUTPUT
@@ -869,7 +870,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         const int coff = cb * BKE + chunk * VEC;
 #pragma unroll
         for (int i = 0; i < XR; ++i) {
-            const int t2 = xt[i] + dt, h2 = xh[i] * a.stride + dh + a.tapShift, w2 = xw[i] * a.stride + dw + a.tapShift;
+            const int t2 = xt[i] + dt;
+            int h2 = xh[i] * a.stride + dh + a.tapShift, w2 = xw[i] * a.stride + dw + a.tapShift;
+            if (a.reflect) {
+                h2 = h2 < 0 ? -h2 : (h2 >= a.Hin ? 2 * a.Hin - 2 - h2 : h2);
+                w2 = w2 < 0 ? -w2 : (w2 >= a.Win ? 2 * a.Win - 2 - w2 : w2);
+            }
             const bool ok = xvalid[i] && (unsigned)t2 < (unsigned)a.T && (unsigned)h2 < (unsigned)a.Hin &&
                             (unsigned)w2 < (unsigned)a.Win;
             const unsigned off = ok ? (unsigned)((((t2 - fb) * a.Hin + h2) * a.Win + w2) * ld + coff) * ESZ : FLAIR_OOB;
@@ -1047,7 +1053,7 @@ int choose_split(const ConvArgs& a, int variant) {
 // 256 workgroups; 0..2: im2col tiles 128 couts x 128 pixels, 64 x 128, 64 x 64.
 // Either way keep >= ~2 workgroups per CU when the problem allows it.
 int choose_variant(const ConvArgs& a) {
-    if (a.stride == 1 && a.KH == 3 && a.KW == 3 && a.W % 32 == 0 && a.H >= 2) {
+    if (!a.reflect && a.stride == 1 && a.KH == 3 && a.KW == 3 && a.W % 32 == 0 && a.H >= 2) {
         const long per = (long)a.T * (a.W / 32) * cdiv(a.Cout, 64);
         // single-round launches (<= one workgroup per CU): K-split kernel, twice the wavefronts
         const bool ks = a.Cout % 8 == 0;
@@ -1092,6 +1098,7 @@ static void fill_geometry(ConvArgs& a, const flair_conv_params* p) {
     a.stride = p->stride > 1 ? p->stride : 1;
     a.Hin = p->H; a.Win = p->W;
     a.T = p->T; a.KT = p->KT; a.KH = p->KH; a.KW = p->KW; a.Cout = p->Cout;
+    a.reflect = p->reflect_pad ? 1 : 0;
     a.H = (p->H + a.stride - 1) / a.stride;       // "same"-style padding K/2: out = ceil(in / stride)
     a.W = (p->W + a.stride - 1) / a.stride;
     a.P = (long)p->T * a.H * a.W;
@@ -1179,6 +1186,9 @@ extern "C" int flair_conv_nhwc(const flair_conv_params* p, const void* const* x,
     FLAIR_CHECK(!p->asym_pad || (a.stride == 2 && a.KH == a.KW && a.KT == 1 && p->H % 2 == 0 && p->W % 2 == 0),
                 "flair_conv_nhwc: asym_pad needs a square 2-D stride-2 kernel on even frames");
     a.tapShift = p->asym_pad ? a.KH / 2 : 0;
+    FLAIR_CHECK(!p->reflect_pad || (!p->asym_pad && a.KT == 1 && p->H > a.KH / 2 && p->W > a.KW / 2),
+                "flair_conv_nhwc: reflect_pad needs a 2-D kernel smaller than the frame");
+    a.reflect = p->reflect_pad ? 1 : 0;
     a.part = nullptr;
     a.splitK = 1;
     {   // A/B switch: 7 selects the register-transposed (v_permlane32_swap) epilogue of the throughput halo kernel

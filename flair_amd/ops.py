@@ -87,7 +87,7 @@ def pad_channels(c, dtype):
 
 # --------------------------------------------------------------------------- conv
 def conv(xs, weight, bias, cout, kernel, *, out=None, act=ACT_NONE, res0=None, res1=None,
-         out_scale=1.0, stride=1, frame_bias=None, act_param=0.0, act_period=0, asym_pad=False):
+         out_scale=1.0, stride=1, frame_bias=None, act_param=0.0, act_period=0, asym_pad=False, reflect_pad=False):
     """Y = act(conv(cat(xs), W) + bias) + res0 + res1, times out_scale.
 
     xs: one clip tensor or a list of up to 4 (channel-concatenated implicitly; each
@@ -112,6 +112,7 @@ def conv(xs, weight, bias, cout, kernel, *, out=None, act=ACT_NONE, res0=None, r
         arr[i] = x.data_ptr()
     p.stride = stride
     p.asym_pad = int(asym_pad)
+    p.reflect_pad = int(reflect_pad)
     p.frame_bias_ld = frame_bias.stride(0) if frame_bias is not None else 0
     if frame_bias is not None:
         assert frame_bias.dtype == torch.float32 and frame_bias.stride(1) == 1 and frame_bias.shape[0] == T

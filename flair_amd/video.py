@@ -9,7 +9,8 @@ frames to the previous window's result (``prev_recon``, gaussian_diffusion.py:49
 contribute only the frames after them (:481-485).
 
 Everything tensor-valued runs through the HIP kernels (resize / clamp / sampler); the face-parsing
-weights and the CodeFormer prior stay the caller's (``vsrpp_weights_fn`` / ``aux_model``).
+weights and the CodeFormer prior are passed in as callables (``vsrpp_weights_fn`` / ``aux_model``; the HIP
+versions are ``workload.parsenet_weights_fn(ParseNet(...), task)`` and ``workload.codeformer_aux(CodeFormer(...))``).
 """
 import torch
 

@@ -110,6 +110,17 @@ def bicubic_taps(factor, a=-0.5):
     return t / t.sum()
 
 
+def parsenet_weights_fn(parser, task):
+    """``vsrpp_weights_fn`` for flair_amd.video built on a ParseNet (flair_amd.guided_diffusion.parsenet): the
+    per-pixel propagation weights of scripts/video_sample.py:427-444 -- background (parsing class 0) pixels get
+    TASKS[task]['face_weight'] (0.93 for x8, 0.98 for x16 bicubic), the rest 1 -- as (1, T, 1, S, S)."""
+    w_face = TASKS[task]["face_weight"]
+
+    def fn(init_norm):                               # (1, T, 3, S, S) in [-1, 1]
+        return parser.face_weight(init_norm[0].float().contiguous(), w_face)[None]
+    return fn
+
+
 def face_weight_map(frames, size, inside):
     """Stand-in for the face-parsing mask of scripts/video_sample.py:427-444: an ellipse of
     background (mask=1 -> weight `inside`... the script weights background pixels) per frame."""

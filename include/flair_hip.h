@@ -100,6 +100,9 @@ typedef struct {
     int asym_pad;    /* 1 (stride 2 only): taps at stride*i .. stride*i + K-1, zeros past the bottom / right edge =
                       * F.pad(x, (0, 1, 0, 1)) + Conv2d(k, stride 2, padding 0), CodeFormer's Downsample
                       * (codeformer.py:138-149); 0: taps centred (padding k//2) */
+    int reflect_pad; /* 1: taps that fall outside the frame read the mirrored pixel (nn.ReflectionPad2d(k//2) + Conv2d
+                      * without padding: ParseNet's ConvLayer, facelib/parsing/parsenet.py:92-104) instead of zeros;
+                      * im2col kernels only (any stride) */
 } flair_conv_params;
 
 size_t flair_conv_workspace_bytes(const flair_conv_params* p);

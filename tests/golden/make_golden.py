@@ -194,7 +194,29 @@ def g9_codeformer():
          param_names=np.array(list(sd.keys())), param_shapes=np.array([";".join(map(str, v.shape)) for v in sd.values()]))
 
 
-EXTRA = {"g4": g4_blocks, "g8": g8_blur_forward, "g5_64": g5_unet_64, "g9": g9_codeformer}
+def g10_parsenet():
+    """G10 (parsing half): the reference's ParseNet as facelib/parsing/__init__.py:13-14 builds it,
+    name-seeded weights and BatchNorm statistics, eval mode.  The file only imports numpy / torch, so it is loaded
+    by path (the facelib package __init__ needs cv2)."""
+    import importlib.util
+    import refimport
+    path = os.path.join(refimport.REFERENCE_ROOT, "guided_diffusion", "facelib", "parsing", "parsenet.py")
+    spec = importlib.util.spec_from_file_location("ref_parsenet", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    net = mod.ParseNet(in_size=512, out_size=512, parsing_ch=19)
+    name_seeded_weights(net)
+    net.eval()
+    x = codeformer_input(batch=1, seed=10)
+    out_mask, out_img = net(x)
+    sd = net.state_dict()
+    save("g10_parsenet", x=x.half(), mask_sub=out_mask[..., ::4, ::4], img_sub=out_img[..., ::4, ::4],
+         argmax=out_mask.argmax(1).to(torch.uint8),
+         margin_sub=(out_mask.topk(2, dim=1)[0][:, 0] - out_mask.topk(2, dim=1)[0][:, 1])[..., ::4, ::4],
+         param_names=np.array(list(sd.keys())), param_shapes=np.array([";".join(map(str, v.shape)) for v in sd.values()]))
+
+
+EXTRA = {"g4": g4_blocks, "g8": g8_blur_forward, "g5_64": g5_unet_64, "g9": g9_codeformer, "g10": g10_parsenet}
 
 
 def main():
