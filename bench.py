@@ -256,7 +256,7 @@ def main():
         aux_model = wl.codeformer_aux(gan)
 
     W = max(0, a.warmup)
-    K = max(1, min(a.steps, TOTAL_STEPS - W - 1))      # keep one step for the instrumented pass
+    K = max(1, min(a.steps, TOTAL_STEPS - W - 2))      # keep two steps for the instrumented pass (eager warm + measured)
     gen = diffusion.p_sample_loop_progressive(
         model, x_T.shape, noise=x_T, clip_denoised=True, model_kwargs=kwargs, device=dev,
         restore_fn=restore_fn, aux_model=aux_model, w=hp["w"], tau=5, aligned=True, rho=hp["rho"],
@@ -285,7 +285,12 @@ def main():
     # ---- roofline leg: one more step with every conv / GroupNorm / alignment / attention call bracketed by
     # HIP events on the launch stream (an empty event pair is measured and subtracted)
     if use_graph:
-        model.enable_hip_graph(False)     # the instrumented step launches eagerly (events around each call)
+        # the instrumented step launches eagerly (events around each call).  The eager path keys its optical-flow cache
+        # on the caller's tensors, not on the graph's static copies: one un-instrumented eager step first, so that the
+        # measured step is a steady-state one (no SPyNet, second-order flows already composed) like the timed steps
+        model.enable_hip_graph(False)
+        next(gen)
+        torch.cuda.synchronize()
     ops.PROFILE = []
     next(gen)
     torch.cuda.synchronize()

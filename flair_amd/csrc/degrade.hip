@@ -83,11 +83,16 @@ __device__ __forceinline__ void dct8x8(const float* D, const float (&in)[8][8], 
         }
 }
 
-__device__ __forceinline__ void codec8x8(const JpegTables& t, const float* q, float (&blk)[8][8]) {
+// lv (or null): where the quantised integer levels of this block go (row stride lvLd) -- what jpeg_encode returns
+__device__ __forceinline__ void codec8x8(const JpegTables& t, const float* q, float (&blk)[8][8], float* lv, int lvLd) {
     float c[8][8];
     dct8x8(t.D, blk, c, false);
     for (int i = 0; i < 8; ++i)
-        for (int j = 0; j < 8; ++j) c[i][j] = rintf(c[i][j] / q[i * 8 + j]) * q[i * 8 + j];  // round half to even
+        for (int j = 0; j < 8; ++j) {
+            const float level = rintf(c[i][j] / q[i * 8 + j]);  // round half to even
+            if (lv) lv[i * lvLd + j] = level;
+            c[i][j] = level * q[i * 8 + j];
+        }
     dct8x8(t.D, c, blk, true);
 }
 
@@ -107,7 +112,7 @@ __global__ void jpeg_to_ycbcr_kernel(const float* x, int N, int S, float* ycc) {
     }
 }
 
-__global__ void jpeg_blocks_kernel(float* ycc, int N, int S, JpegTables t) {
+__global__ void jpeg_blocks_kernel(float* ycc, int N, int S, JpegTables t, float* lumaQ, float* chromaQ) {
     // work items: luma blocks N*(S/8)^2, then chroma blocks 2*N*(S/16)^2
     const int lb = S / 8, cb = S / 16;
     const long nl = (long)N * lb * lb, nc = (long)N * 2 * cb * cb;
@@ -119,7 +124,7 @@ __global__ void jpeg_blocks_kernel(float* ycc, int N, int S, JpegTables t) {
             float* p = ycc + n * 3 * S * S + (long)by * 8 * S + bx * 8;
             for (int r = 0; r < 8; ++r)
                 for (int c = 0; c < 8; ++c) blk[r][c] = p[r * S + c] - 128.f;
-            codec8x8(t, t.q1, blk);
+            codec8x8(t, t.q1, blk, lumaQ ? lumaQ + n * S * S + (long)by * 8 * S + bx * 8 : nullptr, S);
             for (int r = 0; r < 8; ++r)
                 for (int c = 0; c < 8; ++c) p[r * S + c] = blk[r][c] + 128.f;
         } else {
@@ -131,7 +136,8 @@ __global__ void jpeg_blocks_kernel(float* ycc, int N, int S, JpegTables t) {
             float* p = ycc + (n * 3 + 1 + ch) * S * S + (long)by * 16 * S + bx * 16;
             for (int r = 0; r < 8; ++r)
                 for (int c = 0; c < 8; ++c) blk[r][c] = p[2 * r * S + 2 * c] - 128.f;
-            codec8x8(t, t.q2, blk);
+            const int hs = S / 2;
+            codec8x8(t, t.q2, blk, chromaQ ? chromaQ + (n * 2 + ch) * hs * hs + (long)by * 8 * hs + bx * 8 : nullptr, hs);
             for (int r = 0; r < 8; ++r)
                 for (int c = 0; c < 8; ++c) {
                     const float v = blk[r][c] + 128.f;
@@ -215,7 +221,8 @@ extern "C" int flair_depthwise_filter(const float* x, int planes, int Hin, int W
 }
 
 extern "C" int flair_jpeg_roundtrip(const float* x, int N, int S, const float* q_luma, const float* q_chroma,
-                                    const float* dct8, float* workspace, float* y, hipStream_t stream) {
+                                    const float* dct8, float* workspace, float* y, float* luma_q, float* chroma_q,
+                                    hipStream_t stream) {
     FLAIR_CHECK(x && q_luma && q_chroma && dct8 && workspace && y && N > 0 && S > 0 && S % 16 == 0,
                 "flair_jpeg_roundtrip: bad argument (S must be a multiple of 16)");
     JpegTables t;
@@ -227,7 +234,8 @@ extern "C" int flair_jpeg_roundtrip(const float* x, int N, int S, const float* q
     hipLaunchKernelGGL(jpeg_to_ycbcr_kernel, dim3(grid_for((long)N * S * S)), dim3(256), 0, stream, x, N, S, workspace);
     FLAIR_LAUNCH_CHECK();
     const long blocks = (long)N * (S / 8) * (S / 8) + (long)N * 2 * (S / 16) * (S / 16);
-    hipLaunchKernelGGL(jpeg_blocks_kernel, dim3(grid_for(blocks)), dim3(64), 0, stream, workspace, N, S, t);
+    FLAIR_CHECK(!luma_q == !chroma_q, "flair_jpeg_roundtrip: give both level planes or neither");
+    hipLaunchKernelGGL(jpeg_blocks_kernel, dim3(grid_for(blocks)), dim3(64), 0, stream, workspace, N, S, t, luma_q, chroma_q);
     FLAIR_LAUNCH_CHECK();
     hipLaunchKernelGGL(jpeg_to_rgb_kernel, dim3(grid_for((long)N * S * S)), dim3(256), 0, stream, workspace, N, S, y);
     FLAIR_LAUNCH_CHECK();

@@ -48,14 +48,29 @@ def dct8_matrix():
 
 
 class EncodedJpeg:
-    """Result of ``jpeg_encode``: consumed by ``jpeg_decode`` (the planes are not materialised)."""
+    """Result of ``jpeg_encode``: consumed by ``jpeg_decode`` (which runs the whole round trip in one pass).
+    Iterating or indexing it yields what the reference's ``jpeg_encode`` returns -- the quantised integer levels
+    ``[luma (N,1,S,S), chroma (N,2,S/2,S/2)]`` as float tensors (jpeg.py:108-114) -- materialised on demand."""
 
     def __init__(self, image, qf):
         self.image, self.qf = image, qf
+        self._levels = None
+
+    def levels(self):
+        if self._levels is None:
+            q1, q2 = general_quant_matrix(self.qf)
+            self._levels = ops.jpeg_roundtrip(self.image.float().contiguous(), q1, q2, dct8_matrix().reshape(-1),
+                                              want_levels=True)[1]
+        return self._levels
 
     def __iter__(self):
-        raise NotImplementedError("flair_amd: quantised DCT planes are not materialised; "
-                                  "pass the token to jpeg_decode")
+        return iter(self.levels())
+
+    def __getitem__(self, i):
+        return self.levels()[i]
+
+    def __len__(self):
+        return 2
 
 
 def jpeg_encode(x, qf):

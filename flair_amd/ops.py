@@ -589,17 +589,20 @@ def depthwise_filter(x, filt, *, pad, out_stride=1, out_offset=0, stuff=1, stuff
     return out
 
 
-def jpeg_roundtrip(x, q_luma, q_chroma, dct8):
-    """x: (N,3,S,S) f32 in [-1,1]; tables: python sequences / numpy arrays of 64 floats (host)."""
+def jpeg_roundtrip(x, q_luma, q_chroma, dct8, want_levels=False):
+    """x: (N,3,S,S) f32 in [-1,1]; tables: python sequences / numpy arrays of 64 floats (host).
+    want_levels: also return the quantised integer levels [luma (N,1,S,S), chroma (N,2,S/2,S/2)] (f32)."""
     N, C, S, _ = x.shape
     assert C == 3 and x.dtype == torch.float32 and x.is_contiguous()
     arr = ctypes.c_float * 64
     ws = torch.empty_like(x)
     out = torch.empty_like(x)
+    luma = torch.empty((N, 1, S, S), dtype=torch.float32, device=x.device) if want_levels else None
+    chroma = torch.empty((N, 2, S // 2, S // 2), dtype=torch.float32, device=x.device) if want_levels else None
     check(lib().flair_jpeg_roundtrip(ptr(x), N, S, arr(*[float(v) for v in q_luma]),
                                      arr(*[float(v) for v in q_chroma]), arr(*[float(v) for v in dct8]),
-                                     ptr(ws), ptr(out), stream()), "flair_jpeg_roundtrip")
-    return out
+                                     ptr(ws), ptr(out), ptr(luma), ptr(chroma), stream()), "flair_jpeg_roundtrip")
+    return (out, [luma, chroma]) if want_levels else out
 
 
 def matmul(a, b):

@@ -354,9 +354,12 @@ int flair_depthwise_filter(const float* x, int planes, int Hin, int Win, const f
 /* jpeg_decode(jpeg_encode(x, qf), qf) of jpeg.py:72-167 on (N,3,S,S) images in [-1,1].
  * q_luma, q_chroma, dct8 are HOST arrays of 64 floats (quantisation tables of
  * general_quant_matrix, jpeg.py:35-65, and the 8x8 orthonormal DCT-II matrix); workspace:
- * N*3*S*S device floats. */
+ * N*3*S*S device floats.  luma_q / chroma_q (both or neither, may be NULL): the quantised integer
+ * levels round(DCT / q) that jpeg_encode returns (jpeg.py:108-114), as f32 planes (N,1,S,S) and
+ * (N,2,S/2,S/2) in the reference's block layout. */
 int flair_jpeg_roundtrip(const float* x, int N, int S, const float* q_luma, const float* q_chroma,
-                         const float* dct8, float* workspace, float* y, hipStream_t stream);
+                         const float* dct8, float* workspace, float* y, float* luma_q, float* chroma_q,
+                         hipStream_t stream);
 /* C[b] = A[b] (MxK) * B[b] (KxN), row-major f32; a stride of 0 shares the matrix across the
  * batch.  SRConv's separable U/V products (restore_util.py:102-227). */
 int flair_matmul_f32(const float* A, long a_batch_stride, const float* B, long b_batch_stride,

@@ -120,6 +120,36 @@ def test_jpeg_roundtrip_vs_oracle(dev, qf):
     assert frac_bad <= 5e-3, (frac_bad, diff.max().item())
 
 
+@pytest.mark.parametrize("qf", [10, 60, 90])
+def test_jpeg_quantised_levels_bit_exact(dev, qf):
+    """The integer stage of the codec: the levels round(DCT / q) the HIP path quantises to (what the reference's
+    jpeg_encode returns, jpeg.py:108-114) equal the oracle's integers exactly, except where the oracle's own
+    pre-rounding value sits within 2e-3 of a .5 boundary (an f32 last-bit difference in a DCT sum may round either
+    way there); such coefficients must differ by at most one level and be rare."""
+    from flair_amd.guided_diffusion.jpeg import jpeg_encode
+    from oracle import degrade as odeg
+    g = torch.Generator().manual_seed(100 + qf)
+    base = torch.rand(2, 3, 8, 8, generator=g) * 2 - 1
+    x = (torch.nn.functional.interpolate(base, (64, 64), mode="bilinear") + 0.1 * torch.randn(2, 3, 64, 64, generator=g)).clamp(-1, 1)
+    ref_luma, ref_chroma = odeg.jpeg_encode(x, qf)
+    # the oracle's values just before .round(): recompute them with the same helpers
+    xx = (x + 1) / 2 * 255
+    m = torch.tensor([[0.299, 0.587, 0.114], [-0.1687, -0.3313, 0.5], [0.5, -0.4187, -0.0813]])
+    ycc = torch.einsum("nchw,kc->nkhw", xx, m).clone()
+    ycc[:, 1:] += 128
+    q1, q2 = odeg.quant_tables(qf)
+    D = odeg._dct_matrix()
+    pre_l = odeg._unblocks(odeg._lin2d(odeg._blocks(ycc[:, 0:1]).reshape(-1, 8, 8) - 128, D).view(-1, 1, 8, 8) / q1, 2, 1, 64)
+    pre_c = odeg._unblocks(odeg._lin2d(odeg._blocks(ycc[:, 1:, ::2, ::2]).reshape(-1, 8, 8) - 128, D).view(-1, 2, 8, 8) / q2, 2, 2, 32)
+    assert torch.equal(pre_l.round(), ref_luma) and torch.equal(pre_c.round(), ref_chroma)
+    got_luma, got_chroma = (t.cpu() for t in jpeg_encode(x.to(dev), qf))
+    for got, ref, pre in ((got_luma, ref_luma, pre_l), (got_chroma, ref_chroma, pre_c)):
+        assert got.shape == ref.shape and torch.equal(got, got.round())
+        near_tie = ((pre - pre.floor()) - 0.5).abs() < 2e-3
+        assert torch.equal(got[~near_tie], ref[~near_tie])
+        assert (got - ref).abs().max().item() <= 1.0 and near_tie.float().mean().item() < 0.01
+
+
 @pytest.mark.parametrize("f", [8, 16])
 def test_srconv_vs_oracle_and_golden(dev, f):
     """SRConv A / A_pinv (two batched matmuls on the GPU) vs the oracle and the reference's vectors."""
