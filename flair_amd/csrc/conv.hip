@@ -1084,8 +1084,13 @@ int dispatch(const ConvArgs& a0, hipStream_t s) {
         case 2: return launch<E, 64, 64, 2, 2>(a, s);
         case 3: return launch_halo<E, 8, 1, 1>(a, s);
         case 4: return launch_halo<E, 4, 1, 1>(a, s);
-        case 6: return launch_halo_ks<E, 8, 1, 2>(a, s);
-        case 7: return launch_halo_ks<E, 4, 1, 2>(a, s);
+        case 6: {
+            // 8 waves of 2 rows x 64 couts (4 MFMAs per 4 LDS fragment reads) instead of 16 waves of 1 row (2 per 3):
+            // same-box 88.7 -> 88.4 ms/step; FLAIR_KS_RPW2=0 restores the one-row form
+            static const int rpw2 = getenv("FLAIR_KS_RPW2") ? atoi(getenv("FLAIR_KS_RPW2")) : 1;
+            return rpw2 ? launch_halo_ks<E, 8, 2, 2>(a, s) : launch_halo_ks<E, 8, 1, 2>(a, s);
+        }
+        case 7: return launch_halo_ks<E, 4, 1, 2>(a, s);   // (two rows per wave leave 4 waves per CU here: +3.5 ms/step)
         default: return launch_halo<E, 2, 1, 1>(a, s);
     }
 }
