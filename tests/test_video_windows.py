@@ -198,3 +198,73 @@ def test_restore_video_files_matches_in_memory(dev, tmp_path):
     want = fio.to_bytes(ref).cpu().numpy()
     for i in range(N):
         assert np.array_equal(np.asarray(Image.open(tmp_path / "out" / f"{i:04d}.png")), want[i])
+
+
+@pytest.mark.gpu
+def test_window_with_hip_prior_and_parsing_weights(dev):
+    """scripts/video_sample.py:427-479 for one x16-bicubic window at the reference's 512x512: per-pixel
+    ``vsrpp_weights`` from ParseNet's class-0 mask and the CodeFormer prior blended into every step, both on the HIP
+    kernels (workload.parsenet_weights_fn / codeformer_aux), against the same window driven by the CPU oracles of the
+    two networks (2 frames, 2-step chain, toy eps-network; the oracle's code indices are injected so that an arg-max
+    near-tie cannot fork the runs)."""
+    from flair_amd import video
+    from flair_amd import workload as wl
+    from flair_amd.guided_diffusion.codeformer import CodeFormer
+    from flair_amd.guided_diffusion.parsenet import ParseNet
+    from oracle import codeformer as ocf
+    from oracle import parsenet as opn
+    from tests.golden.make_golden import codeformer_input
+    from tests.golden.weights import name_seeded_weights
+    T, S, steps = 2, 512, 2
+    gan = name_seeded_weights(CodeFormer()).eval()
+    parser = name_seeded_weights(ParseNet(in_size=512, out_size=512, parsing_ch=19)).eval()
+    gan_sd = {k: v.detach().clone() for k, v in gan.state_dict().items()}
+    logits_probe = opn.parsenet_forward({k: v.detach().clone() for k, v in parser.state_dict().items()},
+                                        codeformer_input(batch=1, seed=5))[0]
+    with torch.no_grad():      # make the background class cover about half of the frame (see tests/test_parsenet.py)
+        parser.out_mask_conv.conv2d.bias[0] += float((logits_probe[:, 1:].max(1)[0] - logits_probe[:, 0]).median())
+    parser_sd = {k: v.detach().clone() for k, v in parser.state_dict().items()}
+    gan, parser = gan.to(dev), parser.to(dev)
+    g = torch.Generator().manual_seed(77)
+    degraded = ((codeformer_input(batch=T, seed=5)[..., ::16, ::16] + 1) / 2).clamp(0, 1)[None]      # (1, T, 3, 32, 32)
+    tape = [torch.randn(T, 3, S, S, generator=g) for _ in range(steps)]
+    qn = torch.randn(T, 3, S, S, generator=g)
+    diffusion = wl.bicubic_diffusion_for(steps)
+    seen = {}
+
+    class M:
+        def parameters(self):
+            return iter([degraded.to(dev)])
+
+        def __call__(self, x, t, **kw):
+            seen.setdefault("weights", []).append(kw["vsrpp_weights"])
+            lr = kw["low_res_input"][0]
+            return 0.3 * x - 0.2 * lr + 0.05 * torch.roll(x, 1, 0)
+
+    def run(aux_model, weights_fn):
+        seen.clear()
+        out, _ = video.restore_window("x16_bicubic", degraded.to(dev), M(), diffusion, lambda d_n: None, size=S,
+                                      aux_model=aux_model, vsrpp_weights_fn=weights_fn, tau=0,
+                                      noise_fn=lambda wi, it, like: tape[it].to(dev), q_noise_fn=lambda wi, like: qn.to(dev))
+        torch.cuda.synchronize()
+        return out.cpu(), seen["weights"][0].cpu()
+
+    codes = []
+
+    def oracle_aux(x0, *a, **k):
+        out, logits, _ = ocf.codeformer_forward(gan_sd, x0.cpu(), w=1.0, adain=True)
+        codes.append(logits.argmax(2))
+        return out.to(dev)
+
+    def oracle_weights(init_norm):
+        return opn.face_weight(parser_sd, init_norm[0].cpu(), wl.TASKS["x16_bicubic"]["face_weight"])[None].to(dev)
+
+    ref, ref_w = run(oracle_aux, oracle_weights)
+    assert len(codes) == steps
+    it = iter(codes)
+    got, got_w = run(lambda x0, *a, **k: gan(x0, w=1.0, adain=True, code_idx=next(it))[0],
+                     wl.parsenet_weights_fn(parser, "x16_bicubic"))
+    assert got.shape == ref.shape == (T, 3, S, S) and got_w.shape == ref_w.shape == (1, T, 1, S, S)
+    assert (got_w != ref_w).float().mean().item() < 1e-3          # parsing map: equal up to arg-max near-ties
+    assert 0.02 < (ref_w < 1).float().mean().item() < 0.98
+    assert (got - ref).abs().max().item() <= 1e-3
