@@ -12,11 +12,11 @@ import torch
 
 
 def load_reference_checkpoint(model, path, strict=True):
-    """Load a reference checkpoint (a plain state dict, or a dict holding one under ``params_ema`` /
+    """Load a reference checkpoint (a plain state dict, or a dict holding one under ``params_ema`` / ``params`` /
     ``state_dict`` / ``model``) into ``model``; returns torch's missing / unexpected key report."""
     obj = torch.load(path, map_location="cpu", weights_only=True)
     if isinstance(obj, dict):
-        for k in ("params_ema", "state_dict", "model"):
+        for k in ("params_ema", "params", "state_dict", "model"):
             if k in obj and isinstance(obj[k], dict):
                 obj = obj[k]
                 break

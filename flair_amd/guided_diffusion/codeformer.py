@@ -302,7 +302,8 @@ class VQAutoEncoder(nn.Module):
     """codeformer.py:357-434 ('nearest' quantiser; the Gumbel variant and ``model_path`` loading are training-side)."""
 
     def __init__(self, img_size, nf, ch_mult, quantizer="nearest", res_blocks=2, attn_resolutions=(16,),
-                 codebook_size=1024, emb_dim=256, beta=0.25):
+                 codebook_size=1024, emb_dim=256, beta=0.25, gumbel_straight_through=False, gumbel_kl_weight=1e-8,
+                 model_path=None):
         super().__init__()
         if quantizer != "nearest":
             raise NotImplementedError("flair_amd: CodeFormer uses the 'nearest' quantiser")
@@ -312,6 +313,9 @@ class VQAutoEncoder(nn.Module):
         self.encoder = Encoder(3, nf, emb_dim, ch_mult, res_blocks, img_size, self.attn_resolutions)
         self.quantize = VectorQuantizer(codebook_size, emb_dim, beta)
         self.generator = Generator(nf, emb_dim, ch_mult, res_blocks, img_size, self.attn_resolutions)
+        if model_path is not None:                             # {'params_ema' | 'params': state_dict}, :415-428
+            from ..checkpoint import load_reference_checkpoint
+            load_reference_checkpoint(self, model_path)
 
 
 class CodeFormer(VQAutoEncoder):
