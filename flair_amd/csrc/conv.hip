@@ -55,6 +55,7 @@ struct ConvArgs {
     int stride;            // spatial stride (1 or 2; im2col path only)
     int tapShift;          // asym_pad: K/2 added to every spatial tap offset (taps start at stride*i)
     int reflect;           // reflect_pad: out-of-frame taps read the mirrored pixel (im2col path)
+    int ldsSwz;            // halo kernels: conflict-free lane -> staged-row order of the ds_write_b128 (staged_row)
     float actParam;        // FLAIR_ACT_DCN_OFFSETS: max residue magnitude
     int actPeriod;         // FLAIR_ACT_DCN_OFFSETS: 3 * deform groups
     int Hin, Win;          // input frame size (== H, W when stride == 1); H, W, P describe the OUTPUT
@@ -115,6 +116,17 @@ template <> struct Mma<float> {
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {
     return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4);
+}
+
+// 16-byte piece `id` of a staged [rows][64 B] LDS image at 80-byte pitch -> its row (piece = id & 3).  ds_write_b128 is
+// banked (address / 4) % 32 over groups of 8 consecutive lanes (MI355X_MICROARCH.md, LDS): two rows r, r+1 of one group
+// start 20 banks apart and collide on 4 banks (one extra LDS cycle per group: SQ_LDS_BANK_CONFLICT ~ 1 per LDS instruction
+// of the halo kernels, profiles/r02y_conv_pmc_sq.txt), rows r and r+4 start 16 banks apart and fill the 32 banks exactly.
+// So a lane group of 8 stages rows (8k + j, 8k + j + 4).  The switch keeps the linear order for A/B runs.
+__device__ __forceinline__ int staged_row(int id, bool swizzled) {
+    if (!swizzled) return id >> 2;
+    const int g = id >> 3;
+    return (g >> 2) * 8 + (g & 3) + 4 * ((id >> 2) & 1);
 }
 
 // Epilogue for one register quad: 4 consecutive output channels of one pixel.
@@ -179,7 +191,8 @@ void conv3x3_halo_kernel(ConvArgs a) {
     constexpr int NT = 64 * TH / RPW;              // one wavefront per RPW image rows
     constexpr int HW_ = 34;                        // halo width (32 + 2)
     constexpr int PITCH = 80;                      // bytes per staged pixel / weight row
-    constexpr int HALO_PIECES = (TH + 2) * HW_ * 4;
+    constexpr int HALO_ROWS = (TH + 2) * HW_;
+    constexpr int HALO_PIECES = (HALO_ROWS + 7) / 8 * 8 * 4;   // whole groups of 8 rows (see staged_row)
     constexpr int W_PIECES = 64 * 9 * 4;
     constexpr int HI = (HALO_PIECES + NT - 1) / NT;
     constexpr int WI = (W_PIECES + NT - 1) / NT;
@@ -216,10 +229,10 @@ void conv3x3_halo_kernel(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < HI; ++i) {
         const int id = i * NT + tid;
-        const int pix = id >> 2;
+        const int pix = staged_row(id, a.ldsSwz);
         const int r = pix / HW_, c = pix % HW_;
         const int hh = h0 + r - 1, ww = w0 + c - 1;
-        const bool ok = id < HALO_PIECES && (unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W;
+        const bool ok = pix < HALO_ROWS && (unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W;
         hpix[i] = ok ? hh * a.W + ww : -1;
         hq[i] = (id & 3) * VEC * ESZ;
     }
@@ -227,7 +240,7 @@ void conv3x3_halo_kernel(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
         const int id = i * NT + tid;
-        const int row = id >> 2;
+        const int row = staged_row(id, a.ldsSwz);
         const int co = row / 9, tap9 = row % 9;
         const bool ok = id < W_PIECES && co0 + co < a.Cout;
         woff[i] = ok ? (unsigned)(((co0 + co) * taps + tap9) * a.CinTot + (id & 3) * VEC) * ESZ : FLAIR_OOB;
@@ -265,12 +278,13 @@ void conv3x3_halo_kernel(ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < HI; ++i) {
             const int id = i * NT + tid;
-            if (id < HALO_PIECES) *reinterpret_cast<uint4*>(sh + (id >> 2) * PITCH + (id & 3) * 16) = hr[i];
+            const int row = staged_row(id, a.ldsSwz);
+            if (row < HALO_ROWS) *reinterpret_cast<uint4*>(sh + row * PITCH + (id & 3) * 16) = hr[i];
         }
 #pragma unroll
         for (int i = 0; i < WI; ++i) {
             const int id = i * NT + tid;
-            if (id < W_PIECES) *reinterpret_cast<uint4*>(sw + (id >> 2) * PITCH + (id & 3) * 16) = wr[i];
+            if (id < W_PIECES) *reinterpret_cast<uint4*>(sw + staged_row(id, a.ldsSwz) * PITCH + (id & 3) * 16) = wr[i];
         }
     };
     // number of K chunks this workgroup walks (temporal taps outside the clip are skipped)
@@ -550,7 +564,8 @@ __global__ __launch_bounds__(256 * TH / RPW / CF, (256 * TH / RPW / CF) / 256) v
     constexpr int VEC = ET<E>::VEC;
     constexpr unsigned ESZ = sizeof(E);
     constexpr int HW_ = 34, PITCH = 80;
-    constexpr int HALO_PIECES = (TH + 2) * HW_ * 4;
+    constexpr int HALO_ROWS = (TH + 2) * HW_;
+    constexpr int HALO_PIECES = (HALO_ROWS + 7) / 8 * 8 * 4;   // whole groups of 8 rows (see staged_row)
     constexpr int W_PIECES = 64 * 9 * 4;
     constexpr int HI = (HALO_PIECES + NT - 1) / NT;
     constexpr int WI = (W_PIECES + NT - 1) / NT;
@@ -583,10 +598,10 @@ __global__ __launch_bounds__(256 * TH / RPW / CF, (256 * TH / RPW / CF) / 256) v
 #pragma unroll
     for (int i = 0; i < HI; ++i) {
         const int id = i * NT + tid;
-        const int pix = id >> 2;
+        const int pix = staged_row(id, a.ldsSwz);
         const int r = pix / HW_, c = pix % HW_;
         const int hh = h0 + r - 1, ww = w0 + c - 1;
-        const bool ok = id < HALO_PIECES && (unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W;
+        const bool ok = pix < HALO_ROWS && (unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W;
         hpix[i] = ok ? hh * a.W + ww : -1;
         hq[i] = (id & 3) * VEC * ESZ;
     }
@@ -594,7 +609,7 @@ __global__ __launch_bounds__(256 * TH / RPW / CF, (256 * TH / RPW / CF) / 256) v
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
         const int id = i * NT + tid;
-        const int row = id >> 2;
+        const int row = staged_row(id, a.ldsSwz);
         const int co = row / 9, tap9 = row % 9;
         const bool ok = id < W_PIECES && co0 + co < a.Cout;
         woff[i] = ok ? (unsigned)(((co0 + co) * taps + tap9) * a.CinTot + (id & 3) * VEC) * ESZ : FLAIR_OOB;
@@ -629,12 +644,13 @@ __global__ __launch_bounds__(256 * TH / RPW / CF, (256 * TH / RPW / CF) / 256) v
 #pragma unroll
         for (int i = 0; i < HI; ++i) {
             const int id = i * NT + tid;
-            if (id < HALO_PIECES) *reinterpret_cast<uint4*>(sh + (id >> 2) * PITCH + (id & 3) * 16) = hreg[i];
+            const int row = staged_row(id, a.ldsSwz);
+            if (row < HALO_ROWS) *reinterpret_cast<uint4*>(sh + row * PITCH + (id & 3) * 16) = hreg[i];
         }
 #pragma unroll
         for (int i = 0; i < WI; ++i) {
             const int id = i * NT + tid;
-            if (id < W_PIECES) *reinterpret_cast<uint4*>(sw + (id >> 2) * PITCH + (id & 3) * 16) = wreg[i];
+            if (id < W_PIECES) *reinterpret_cast<uint4*>(sw + staged_row(id, a.ldsSwz) * PITCH + (id & 3) * 16) = wreg[i];
         }
     };
     int nValidDt = 0;
@@ -1194,6 +1210,10 @@ extern "C" int flair_conv_nhwc(const flair_conv_params* p, const void* const* x,
     FLAIR_CHECK(!p->reflect_pad || (!p->asym_pad && a.KT == 1 && p->H > a.KH / 2 && p->W > a.KW / 2),
                 "flair_conv_nhwc: reflect_pad needs a 2-D kernel smaller than the frame");
     a.reflect = p->reflect_pad ? 1 : 0;
+    {
+        static const int swz = getenv("FLAIR_CONV_LDS_SWZ") ? atoi(getenv("FLAIR_CONV_LDS_SWZ")) : 1;
+        a.ldsSwz = swz;
+    }
     a.part = nullptr;
     a.splitK = 1;
     {   // A/B switch: 7 selects the register-transposed (v_permlane32_swap) epilogue of the throughput halo kernel
