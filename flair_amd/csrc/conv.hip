@@ -1101,9 +1101,10 @@ int dispatch(const ConvArgs& a0, hipStream_t s) {
         case 3: return launch_halo<E, 8, 1, 1>(a, s);
         case 4: return launch_halo<E, 4, 1, 1>(a, s);
         case 6: {
-            // 8 waves of 2 rows x 64 couts (4 MFMAs per 4 LDS fragment reads) instead of 16 waves of 1 row (2 per 3):
-            // same-box 88.7 -> 88.4 ms/step; FLAIR_KS_RPW2=0 restores the one-row form
-            static const int rpw2 = getenv("FLAIR_KS_RPW2") ? atoi(getenv("FLAIR_KS_RPW2")) : 1;
+            // FLAIR_KS_RPW2=1: 8 waves of 2 rows x 64 couts (4 MFMAs per 4 LDS fragment reads) instead of 16 waves of 1 row
+            // (2 per 3).  Neutral end to end (90.95 vs 90.84 ms/step, three same-box pairs) and slower per call under
+            // rocprofv3 (26.1 vs 22.9 us): the one-row form stays the default.
+            static const int rpw2 = getenv("FLAIR_KS_RPW2") ? atoi(getenv("FLAIR_KS_RPW2")) : 0;
             return rpw2 ? launch_halo_ks<E, 8, 2, 2>(a, s) : launch_halo_ks<E, 8, 1, 2>(a, s);
         }
         case 7: return launch_halo_ks<E, 4, 1, 2>(a, s);   // (two rows per wave leave 4 waves per CU here: +3.5 ms/step)
