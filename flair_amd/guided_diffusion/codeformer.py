@@ -352,6 +352,11 @@ class CodeFormer(VQAutoEncoder):
         self._packed_key = None
         return self
 
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self._packed_key = None                 # kernel-native weight copies are rebuilt on the next forward
+        return out
+
     def _ensure_packed(self, device):
         key = (self.dtype, device)
         if self._packed_key == key:

@@ -125,6 +125,11 @@ class ParseNet(nn.Module):
         self.dtype = torch.float32
         self._packed_key = None
 
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self._packed_key = None                 # folded / packed weights are rebuilt on the next forward
+        return out
+
     def _ensure_packed(self, device):
         key = (self.dtype, device)
         if self._packed_key != key:
