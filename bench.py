@@ -62,6 +62,22 @@ def pmc_traffic_for(kernel_fmt, dkey):
     return None, None
 
 
+def cpu_baseline_prior():
+    """cpu_baseline leg of `--aux codeformer`: the oracle's CodeFormer (port, torch CPU fp32) on ONE aligned 512x512 face,
+    as the sampler calls it (w = 1, AdaIN), with the same default-initialised weights as the benched HIP module."""
+    from flair_amd.guided_diffusion.codeformer import CodeFormer
+    from oracle import codeformer as ocf
+    torch.manual_seed(1)
+    sd = {k: v.detach().float() for k, v in CodeFormer(dim_embd=512, codebook_size=1024, n_head=8, n_layers=9,
+                                                        connect_list=["32", "64", "128", "256"]).state_dict().items()}
+    x = torch.rand(1, 3, 512, 512, generator=torch.Generator().manual_seed(0)) * 2 - 1
+    ocf.codeformer_forward(sd, x, w=1.0, adain=True)
+    t0 = time.time()
+    ocf.codeformer_forward(sd, x, w=1.0, adain=True)
+    return {"kind": "port", "cores": torch.get_num_threads(), "s_per_face": time.time() - t0,
+            "sample": "oracle/codeformer.py, one 512x512 face, fp32"}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -377,6 +393,8 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(S, T)
+                if a.aux == "codeformer":
+                    line["cpu_baseline"]["aux_prior"] = cpu_baseline_prior()
             except Exception as exc:  # the baseline must never hide the measurement
                 line["cpu_baseline"] = {"value": None, "error": repr(exc)}
         print(json.dumps(line), flush=True)

@@ -1,7 +1,7 @@
 """CodeFormer auxiliary prior on one window of aligned 512x512 faces: ms per call, conv TFLOP/s
-from the per-call HIP events of ops.PROFILE, and the oracle (CPU port) timed on one face beside it.
+from the per-call HIP events of ops.PROFILE.  (The CPU port is timed by `bench.py --aux codeformer`'s cpu_baseline leg.)
 
-    python tools/bench_codeformer.py [--frames 10] [--json out.json] [--no-cpu]
+    python tools/bench_codeformer.py [--frames 10] [--json out.json]
 """
 import argparse
 import json
@@ -24,7 +24,6 @@ def main():
     ap.add_argument("--frames", type=int, default=10, help="faces per call (the reference's window is 10 frames)")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--json", default=None)
-    ap.add_argument("--no-cpu", action="store_true")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     model = name_seeded_weights(CodeFormer()).to(dev).eval()
@@ -59,17 +58,6 @@ def main():
                      "whole_call_tflops": conv[1] / (ms * 1e-3) / 1e12,
                      "families_ms": {k: round(v[3], 3) for k, v in fam.items()}}
         print(name, json.dumps(res[name]), flush=True)
-    if not a.no_cpu:
-        from oracle import codeformer as ocf
-        sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
-        x1 = x[:1].cpu()
-        ocf.codeformer_forward(sd, x1, w=1.0, adain=True)
-        t0 = time.perf_counter()
-        ocf.codeformer_forward(sd, x1, w=1.0, adain=True)
-        s = time.perf_counter() - t0
-        res["cpu_baseline"] = {"kind": "port", "cores": torch.get_num_threads(), "s_per_face": s,
-                               "sample": "one 512x512 face, oracle/codeformer.py, fp32"}
-        print("cpu", json.dumps(res["cpu_baseline"]), flush=True)
     if a.json:
         with open(a.json, "w") as f:
             json.dump(res, f, indent=1)

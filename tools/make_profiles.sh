@@ -30,8 +30,9 @@ bash tools/ab_bench.sh $OUT/ab > /dev/null 2>&1
 cat $OUT/ab/ab.log
 # rows 8f-1 / 8f-4: the CodeFormer prior alone, and the 512^2 x 10-frame step without / with it
 timeout -k 10 300 python tools/bench_codeformer.py --json $OUT/codeformer.json > $OUT/codeformer.txt 2>/dev/null
-for aux in "--aux identity" "--aux codeformer" "--aux codeformer --aux-dtype bf16"; do
-  timeout -k 10 600 python bench.py --size 512 --frames 10 --steps 6 --warmup 1 --no-cpu-baseline $aux 2>/dev/null | tail -1 >> $OUT/bench_512x10_aux.jsonl
+rm -f $OUT/bench_512x10_aux.jsonl
+for aux in "--no-cpu-baseline --aux identity" "--aux codeformer" "--no-cpu-baseline --aux codeformer --aux-dtype bf16"; do   # the f32 line carries the CPU legs
+  timeout -k 10 900 python bench.py --size 512 --frames 10 --steps 6 --warmup 1 $aux 2>/dev/null | tail -1 >> $OUT/bench_512x10_aux.jsonl
 done
 cut -c1-220 $OUT/bench_512x10_aux.jsonl
 bash tools/run_trace_all.sh gpurun_out/$TAG/trace > /dev/null 2>&1
