@@ -102,6 +102,15 @@ class GaussianDiffusion:
         self.posterior_mean_coef4 = self.posterior_mean_coef2 * np.sqrt(1 - self.alphas_cumprod)
 
     # ------------------------------------------------------------------ forward process
+    def q_mean_variance(self, x_start, t):
+        """Mean / variance / log-variance of q(x_t | x_0) (gaussian_diffusion.py:189-204); uniform t."""
+        i = _uniform_step(t)
+        f32 = lambda v: float(np.float32(v))  # noqa: E731
+        x = x_start.float().contiguous()
+        mean = ops.axpby(x, x, f32(self.sqrt_alphas_cumprod[i]), 0.0)
+        return (mean, th.full_like(mean, f32(1.0 - self.alphas_cumprod[i])),
+                th.full_like(mean, f32(self.log_one_minus_alphas_cumprod[i])))
+
     def q_sample(self, x_start, t, noise=None):
         """sqrt(acp_t) x0 + sqrt(1-acp_t) eps (gaussian_diffusion.py:206-224); uniform t."""
         if noise is None:

@@ -51,7 +51,7 @@ def test_script_imports_bind_to_flair_amd():
                             model_var_type=ModelVarType.LEARNED_RANGE, loss_type=LossType.RESCALED_MSE,
                             rescale_timesteps=False)
         assert d.num_timesteps == 100
-        for name in ("q_posterior_mean_variance", "_predict_xstart_from_eps", "_predict_eps_from_xstart",
+        for name in ("q_mean_variance", "q_posterior_mean_variance", "_predict_xstart_from_eps", "_predict_eps_from_xstart",
                      "p_mean_variance", "p_sample", "p_sample_loop", "p_sample_loop_progressive", "sample", "q_sample"):
             assert callable(getattr(d, name)), name
         print("ok")

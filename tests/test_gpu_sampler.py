@@ -213,6 +213,11 @@ def test_p_mean_variance_moments(dev, learned):
     for name, ref in (("pred_xstart", x0), ("mean", mean), ("variance", var), ("log_variance", logvar)):
         err = (got[name].cpu() - ref).abs().max().item()
         assert err <= 2e-5 * max(1.0, ref.abs().max().item()), (name, err)
+    # q(x_t | x_0) moments (gaussian_diffusion.py:189-204) from the same tables
+    qm, qv, qlv = d.q_mean_variance(x.to(dev), t.to(dev))
+    assert (qm.cpu() - f(tab.sqrt_alphas_cumprod) * x).abs().max().item() <= 2e-6
+    assert abs(float(qv.flatten()[0]) - (1.0 - tab.alphas_cumprod[i])) <= 1e-6 and qv.shape == x.shape
+    assert abs(float(qlv.flatten()[0]) - np.log(1.0 - tab.alphas_cumprod[i])) <= 1e-5
 
 
 def test_full_chain_real_network_vs_oracle(dev):
