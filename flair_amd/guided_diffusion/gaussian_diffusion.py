@@ -33,6 +33,14 @@ def get_named_beta_schedule(schedule_name, num_diffusion_timesteps):
     raise NotImplementedError(f"unknown beta schedule: {schedule_name}")
 
 
+def betas_for_alpha_bar(num_diffusion_timesteps, alpha_bar, max_beta=0.999):
+    """gaussian_diffusion.py:39-56: betas that discretise a cumulative-product function alpha_bar(t), t in [0, 1]
+    (host helper; neither named schedule of the reference uses it)."""
+    steps = np.arange(num_diffusion_timesteps + 1) / num_diffusion_timesteps
+    bar = np.array([alpha_bar(t) for t in steps], dtype=np.float64)
+    return np.minimum(1 - bar[1:] / bar[:-1], max_beta)
+
+
 class ModelMeanType(enum.Enum):
     PREVIOUS_X = enum.auto()
     START_X = enum.auto()
