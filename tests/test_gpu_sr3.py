@@ -116,3 +116,28 @@ def test_gated_blend_and_sin_first_encoding(dev):
     assert (from_clip(y) - ref).abs().max().item() <= 1e-5
     lv = torch.tensor([0.1, 0.83, 1.0])
     assert (ops.timestep_embedding(lv.to(dev), 64, sin_first=True).cpu() - PositionalEncoding(64)(lv)).abs().max() <= 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tensor_weights", [False, True])
+def test_sr3_hip_graph_replay_matches_eager(dev, tensor_weights):
+    """sr3.UNet.enable_hip_graph(): the captured forward replays bit-identically to eager launches for new latents /
+    noise levels, after the conditioning clip changes, and with the per-pixel propagation-weight map of the bicubic
+    tasks (a tensor input of the graph)."""
+    _, m = build_pair()
+    m = m.to(dev)
+    m.convert_to_fp16()
+    T, S = 4, 64
+    g = torch.Generator().manual_seed(2)
+    wmap = (0.9 + 0.1 * torch.rand(1, T, 1, S, S, generator=g)).to(dev) if tensor_weights else 0.93
+    cases = []
+    for seed, lvl in [(5, 0.83), (5, 0.31), (9, 0.97)]:        # same clip twice, then a new clip
+        x, lr, level = inputs(T, S, seed=seed)
+        cases.append(((x + lvl).to(dev), lr.to(dev), torch.full((T,), lvl).to(dev)))
+    eager = [m(x, lv, low_res_input=lr, num_frames=T, vsrpp_weights=wmap).clone() for x, lr, lv in cases]
+    m.enable_hip_graph()
+    for (x, lr, lv), ref in zip(cases, eager):
+        y = m(x, lv, low_res_input=lr, num_frames=T, vsrpp_weights=wmap)
+        torch.cuda.synchronize()
+        assert torch.equal(y, ref)
+    m.enable_hip_graph(False)
