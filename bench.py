@@ -157,34 +157,103 @@ def cpu_baseline(size, frames):
                       f"frames x pixels (x{scale:.0f}) to the benched {frames} x {size}x{size}, {TOTAL_STEPS}-step job"}
 
 
-def spawn_ranks(n):
+def visible_gpu_count():
+    """GPUs this process may use, counted WITHOUT touching the HIP runtime (the parent only spawns the rank processes and
+    must never initialise the GPU): KFD topology nodes with SIMDs, narrowed by *_VISIBLE_DEVICES.  None if unknown."""
+    import glob
+    n = 0
+    try:
+        for path in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+            with open(path) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except (OSError, ValueError):
+        return None
+    if n == 0:
+        return None
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([d for d in v.split(",") if d.strip() != ""]))
+    return n
+
+
+def spawn_ranks(n, wall_limit_s=None):
     """`python bench.py --gpus N` without a launcher: start N rank processes (one per GPU) from this
-    process, which has not touched the GPU, and relay rank 0's JSON line.  Children get the same
-    environment torch.distributed.run would give them."""
+    process, which never touches the GPU, and relay rank 0's JSON line.  Children get the same
+    environment torch.distributed.run would give them.  All children are polled: when one exits non-zero,
+    or the wall limit passes, the others are terminated and this process exits non-zero with the tail of
+    the failing rank's stderr (a rank that dies inside RCCL initialisation must not leave rank 0 hanging)."""
     import socket
     import subprocess
+    import tempfile
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = []
+    wall_limit_s = wall_limit_s or float(os.environ.get("FLAIR_BENCH_WALL_LIMIT_S", "1500"))
+    procs, logs = [], []
+    tmp = tempfile.mkdtemp(prefix="flair_bench_")
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        out = open(os.path.join(tmp, f"rank{r}.out"), "w+b")
+        err = open(os.path.join(tmp, f"rank{r}.err"), "w+b")
+        logs.append((out, err))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+                                      stdout=out, stderr=err, start_new_session=True))
+
+    def tail(f, nbytes=4000):
+        f.flush()
+        f.seek(0, 2)
+        size = f.tell()
+        f.seek(max(0, size - nbytes))
+        return f.read().decode("utf-8", "replace")
+
+    def stop_all():
+        for q in procs:
+            if q.poll() is None:
+                q.terminate()
+        t_end = time.time() + 10
+        for q in procs:
+            try:
+                q.wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                q.kill()
+
+    t0 = time.time()
+    failed = None
+    while True:
+        codes = [q.poll() for q in procs]
+        bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = (bad[0], f"rank {bad[0]} exited with status {codes[bad[0]]}")
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.time() - t0 > wall_limit_s:
+            failed = (0, f"wall limit of {wall_limit_s:.0f} s passed (ranks still running: "
+                         f"{[r for r, c in enumerate(codes) if c is None]})")
+            break
+        time.sleep(0.2)
+    if failed is not None:
+        stop_all()
+        r, why = failed
+        sys.stderr.write(f"bench.py --gpus {n}: {why}; stderr tail of rank {r}:\n{tail(logs[r][1])}\n")
+        sys.stderr.flush()
+        return 1
+    sys.stdout.write(tail(logs[0][0], 1 << 20))
     sys.stdout.flush()
-    return max(abs(c) for c in codes)
+    sys.stderr.write(tail(logs[0][1]))
+    return 0
 
 
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        n_dev = torch.cuda.device_count()       # counting devices does not initialise the GPU runtime
-        if n_dev < a.gpus:
+        n_dev = visible_gpu_count()             # sysfs only: the parent never loads the HIP runtime
+        if n_dev is not None and n_dev < a.gpus:
             raise SystemExit(f"--gpus {a.gpus} requested but only {n_dev} GPU(s) are visible")
         raise SystemExit(spawn_ranks(a.gpus))
     rank = int(os.environ.get("RANK", "0"))
@@ -225,6 +294,12 @@ def main():
         model.convert_to_fp16()
     # one kernel-native (bf16-packed) weight blob from rank 0 over RCCL; the other ranks never repack
     t_bcast, bcast_bytes = parallel.broadcast_packed_weights(model, src=0) if world > 1 else (0.0, 0)
+    bcast_per_rank = [{"rank": 0, "s": t_bcast, "bytes": bcast_bytes}]
+    if world > 1:       # every rank's own view of the start-up weight distribution (seconds, bytes received)
+        mine = torch.tensor([t_bcast, float(bcast_bytes)], device=dev, dtype=torch.float64)
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        bcast_per_rank = [{"rank": r, "s": float(v[0]), "bytes": int(v[1])} for r, v in enumerate(allv)]
     use_graph = a.graph and hasattr(model, "enable_hip_graph")
     if use_graph:
         model.enable_hip_graph()          # one hipGraph per clip shape: ~3300 launches become one replay
@@ -298,12 +373,16 @@ def main():
         elapsed = float(tmax.item())
     finite = bool(torch.isfinite(out["sample"]).all().item())
 
-    # ---- roofline leg: one more step with every conv / GroupNorm / alignment / attention call bracketed by
-    # HIP events on the launch stream (an empty event pair is measured and subtracted)
+    # ---- roofline leg.  One more (eagerly launched, steady-state) step records every conv / GroupNorm / alignment / warp /
+    # attention call together with a closure that re-issues the identical library call.  Every DISTINCT launch shape is then
+    # timed on its own: a hipGraph of REPLAY_N back-to-back launches of that call on the launch stream, bracketed by HIP
+    # events (minimum of three replays / REPLAY_N).  A family's time is sum(count x per-launch time): no empty-event gap is
+    # subtracted anywhere, and the figure is directly comparable with rocprofv3's average duration of the same kernel
+    # (profiles/r03*_kernel_stats.csv); the raw in-situ event time of the step is reported next to it.
     if use_graph:
-        # the instrumented step launches eagerly (events around each call).  The eager path keys its optical-flow cache
-        # on the caller's tensors, not on the graph's static copies: one un-instrumented eager step first, so that the
-        # measured step is a steady-state one (no SPyNet, second-order flows already composed) like the timed steps
+        # the instrumented step launches eagerly.  The eager path keys its optical-flow cache on the caller's tensors, not
+        # on the graph's static copies: one un-instrumented eager step first, so that the measured step is a steady-state
+        # one (no SPyNet, second-order flows already composed) like the timed steps
         model.enable_hip_graph(False)
         next(gen)
         torch.cuda.synchronize()
@@ -311,38 +390,72 @@ def main():
     next(gen)
     torch.cuda.synchronize()
     prof, ops.PROFILE = ops.PROFILE, None
-    gaps = []
-    for _ in range(64):
-        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        c0.record()
-        c1.record()
-        gaps.append((c0, c1))
-    torch.cuda.synchronize()
-    gap_ms = sorted(c0.elapsed_time(c1) for c0, c1 in gaps)[len(gaps) // 2]
+    REPLAY_N = 10
+
+    def replay_us(fn):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        g_ = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            fn()
+            with torch.cuda.graph(g_, stream=side, capture_error_mode="thread_local"):
+                for _ in range(REPLAY_N):
+                    fn()
+        torch.cuda.current_stream().wait_stream(side)
+        g_.replay()
+        torch.cuda.synchronize()
+        best = None
+        for _ in range(3):
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0.record()
+            g_.replay()
+            c1.record()
+            torch.cuda.synchronize()
+            us_ = c0.elapsed_time(c1) * 1e3 / REPLAY_N
+            best = us_ if best is None else min(best, us_)
+        return best
+
+    sig_us = {}
+    for fam, dt_name, flops, nbytes, e0, e1, replay, sig in prof:
+        k_ = (fam, dt_name, sig)
+        if k_ not in sig_us:
+            sig_us[k_] = replay_us(replay)
     per = {}
-    for fam, dt_name, flops, nbytes, e0, e1 in prof:
-        d = per.setdefault((fam, dt_name), [0, 0.0, 0.0, 0.0])
+    for fam, dt_name, flops, nbytes, e0, e1, replay, sig in prof:
+        d = per.setdefault((fam, dt_name), [0, 0.0, 0.0, 0.0, 0.0])
         d[0] += 1
         d[1] += flops
         d[2] += nbytes
-        d[3] += max(e0.elapsed_time(e1) - gap_ms, 1e-4) * 1e-3
+        d[3] += sig_us[(fam, dt_name, sig)] * 1e-6
+        d[4] += e0.elapsed_time(e1) * 1e-3            # raw in-situ events (launch gap included)
     conv_keys = [k for k in per if k[0][0] == "conv"]
     key = max(conv_keys, key=lambda k: per[k][3])
-    calls, flops, _, secs = per[key]
+    calls, flops, _, secs, secs_events = per[key]
     achieved = flops / secs / 1e12
     dkey = "bf16" if "bfloat16" in key[1] else "f32"
     peak = MFMA_PEAK_TFLOPS[dkey]
     all_flops = sum(per[k][1] for k in conv_keys)
     all_secs = sum(per[k][3] for k in conv_keys)
     step_s = elapsed / K
+    # the dominant kernel by launch shape
+    by_shape = []
+    for (fam, dt_name, sig), us_ in sig_us.items():
+        if (fam, dt_name) != key:
+            continue
+        ent_ = [e for e in prof if e[0] == fam and e[1] == dt_name and e[7] == sig]
+        by_shape.append({"shape": {"T": sig[1], "H": sig[2], "W": sig[3], "cin": list(sig[4]), "cout": sig[5], "kernel": list(sig[6])},
+                         "launches": len(ent_), "us_per_launch": us_, "TFLOP/s": ent_[0][2] / us_ / 1e6,
+                         "frac": ent_[0][2] / us_ / 1e6 / peak})
+    by_shape.sort(key=lambda e_: -e_["launches"] * e_["us_per_launch"])
 
     def family(pred, bound, label):
         ks = [k for k in per if pred(k[0])]
         if not ks:
             return None
         n = sum(per[k][0] for k in ks)
-        fl, by, se = (sum(per[k][i] for k in ks) for i in (1, 2, 3))
-        ent = {"family": label, "bound": bound, "launches": n, "ms_per_step": 1e3 * se, "share_of_step": se / step_s}
+        fl, by, se, sev = (sum(per[k][i] for k in ks) for i in (1, 2, 3, 4))
+        ent = {"family": label, "bound": bound, "launches": n, "ms_per_step": 1e3 * se, "share_of_step": se / step_s,
+               "ms_per_step_in_situ_events": 1e3 * sev}
         if bound == "mfma":
             pk = MFMA_PEAK_TFLOPS["bf16" if "bfloat16" in ks[0][1] else "f32"]
             ent.update(achieved=fl / se / 1e12, peak=pk, unit="TFLOP/s", frac=fl / se / 1e12 / pk)
@@ -360,9 +473,58 @@ def main():
         family(lambda f: f[0] == "dcn" and f[1] <= 64, "hbm", "deformable alignment c=64 (dcn_kernel), bytes = esz*(3c+432)*H*W"),
         family(lambda f: f[0] == "dcn" and f[1] > 64, "hbm", "deformable alignment c=128 (dcn_kernel), bytes = esz*(3c+432)*H*W"),
         family(lambda f: f[0] == "prep", "hbm", "flow warp + compose of one propagation step (vsrpp_prep_kernel)"),
-        family(lambda f: f[0] == "attn", "mfma", "spatial QKVAttention in situ (attn_mfma_bf16_kernel; isolated numbers: profiles/)"),
+        family(lambda f: f[0] == "attn", "mfma", "spatial QKVAttention in situ (attn_mfma_bf16_kernel; isolated: attention_isolated)"),
     ]
     fams = [f for f in fams if f]
+
+    # ---- north_star target 1: the ResBlock conv path against the HBM roofline.  One level-0 2-D ResBlock (GroupNorm+SiLU ->
+    # conv3x3 -> GroupNorm*(1+scale)+shift+SiLU -> conv3x3 + skip on the (T, S, S, c0) tensor): SURVEY 8a/8d's minimum
+    # traffic = 7 passes over the activation (statistics read + normalise-on-load read + write, twice, + the residual read
+    # = 0.94 GB at 16 x 256^2 x 64 bf16) over the measured time of its two norms and two convolutions.
+    resblock_path = None
+    esz_act = 2 if a.dtype == "bf16" else 4
+    c0 = None
+    for (fam, dt_name, sig), us_ in sig_us.items():
+        if fam[0] == "conv" and sig[1:4] == (T, S, S) and len(sig[4]) == 1 and sig[4][0] == sig[5] and tuple(sig[6]) == (1, 3, 3) \
+                and sig[7] == 1 and sig[9] and not sig[10]:          # conv2 of the block: c -> c with the skip as res0
+            c0 = sig[5]
+            conv2_us = us_
+    if c0 is not None:
+        def pick(pred):
+            v = [us_ for (fam, dt_name, sig), us_ in sig_us.items() if pred(fam, sig)]
+            return v[0] if v else None
+        conv1_us = pick(lambda fam, sig: fam[0] == "conv" and sig[1:4] == (T, S, S) and sig[4] == (c0,) and sig[5] == c0
+                        and tuple(sig[6]) == (1, 3, 3) and not sig[9] and sig[8] == 0)
+        gn1_us = pick(lambda fam, sig: fam[0] == "gn" and sig[1:5] == (T, S, S, c0) and sig[5] == c0 and sig[9] == 0
+                      and not sig[10] and not sig[11])
+        gn2_us = pick(lambda fam, sig: fam[0] == "gn" and sig[1:5] == (T, S, S, c0) and sig[5] == c0 and sig[9] == 0
+                      and not sig[10] and sig[11])
+        if None not in (conv1_us, gn1_us, gn2_us):
+            act_bytes = esz_act * T * S * S * c0
+            tot_us = conv1_us + conv2_us + gn1_us + gn2_us
+            resblock_path = {"block": f"level-0 2-D ResBlock, ({T},{S},{S},{c0}) {a.dtype}", "bound": "hbm",
+                             "algorithmic_bytes": 7 * act_bytes, "us": {"gn1": gn1_us, "conv1": conv1_us, "gn2": gn2_us,
+                                                                        "conv2": conv2_us, "total": tot_us},
+                             "achieved": 7 * act_bytes / tot_us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": 7 * act_bytes / tot_us / 1e3 / HBM_PEAK_GBS, "target_frac": 0.70,
+                             "bytes_actually_moved": 11 * act_bytes,
+                             "note": "7 activation passes = SURVEY 8d minimum (0.94 GB at 16x256^2x64 bf16); the unfused pipeline "
+                                     "moves 11 (two-pass norm x2, conv read+write x2, residual read)"}
+
+    # ---- north_star target 2: QKVAttention against the MFMA peak, isolated (replay-timed) at L = 256 (config 2's own
+    # attention blocks), 1024 and 4096 tokens; 16 frames, heads of width 64; FLOPs = 4 * frames * heads * L^2 * 64
+    attention_isolated = []
+    if a.dtype == "bf16":
+        for L_, C_, heads_ in ((256, 256, 4), (1024, 256, 4), (4096, 128, 2)):
+            side_ = int(L_ ** 0.5)
+            qkv_ = torch.randn(16, side_, side_, 3 * C_, device=dev).to(torch.bfloat16)
+            out_ = ops.qkv_attention(qkv_, heads_)
+            us_ = replay_us(lambda: ops.qkv_attention(qkv_, heads_, out=out_))
+            fl_ = 4.0 * 16 * heads_ * L_ * L_ * 64
+            attention_isolated.append({"L": L_, "frames": 16, "heads": heads_, "us_per_launch": us_, "GFLOP": fl_ / 1e9,
+                                       "achieved": fl_ / us_ / 1e6, "peak": MFMA_PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
+                                       "frac": fl_ / us_ / 1e6 / MFMA_PEAK_TFLOPS["bf16"], "target_frac": 0.50})
+            del qkv_, out_
     traffic, traffic_src = pmc_traffic_for(CONV_ROCPROF.get(key[0][1], ""), dkey)
     ms_per_step = 1e3 * elapsed / K
     value = world * T / (TOTAL_STEPS * elapsed / K)
@@ -377,7 +539,8 @@ def main():
                                   "unet_new.UNetModel 405.6M params random init, blur x4 restore_fn on GPU")
                                + ", one clip per GPU",
                    "steps_per_clip": TOTAL_STEPS, "value_definition": f"n_gpus*frames/({TOTAL_STEPS}*mean timed step)",
-                   "finite_output": finite, "weight_broadcast_s": t_bcast, "weight_broadcast_bytes": bcast_bytes,
+                   "finite_output": finite, "weight_broadcast_s": max(b["s"] for b in bcast_per_rank),
+                   "weight_broadcast_bytes": bcast_bytes, "weight_broadcast_per_rank": bcast_per_rank,
                    "hip_graph": use_graph,
                    "aux_prior": "identity" if a.aux == "identity" else f"CodeFormer (HIP, {a.aux_dtype}) every step t >= tau"},
         "roofline": {"bound": "mfma", "kernel": CONV_VARIANTS.get(key[0][1], str(key[0][1])) + " " + key[1],
@@ -385,8 +548,15 @@ def main():
                      "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
                      "traffic_source": traffic_src, "algorithmic_bytes_per_launch": per[key][2] / calls,
                      "launches": calls, "avg_launch_us": 1e6 * secs / calls,
+                     "avg_launch_us_in_situ_events": 1e6 * secs_events / calls,
+                     "timing": f"per distinct launch shape: hipGraph of {REPLAY_N} back-to-back launches between HIP events on the "
+                               "launch stream, min of 3 replays; no gap subtracted (compare: rocprofv3 average duration of the "
+                               "same kernel in profiles/)",
+                     "by_shape": by_shape,
                      "all_conv_achieved": all_flops / all_secs / 1e12,
                      "all_conv_share_of_step": all_secs / (ms_per_step * 1e-3),
+                     "resblock_path": resblock_path,
+                     "attention_isolated": attention_isolated,
                      "families": fams},
     }
     if rank == 0:

@@ -530,6 +530,12 @@ extern "C" int flair_conv_chain(const flair_chain_params* p, const void* const* 
     FLAIR_CHECK(p->actA != FLAIR_ACT_DCN_OFFSETS && (p->actB != FLAIR_ACT_DCN_OFFSETS ||
                                                        (p->act_period > 0 && p->act_period % 24 == 0)),
                 "flair_conv_chain: FLAIR_ACT_DCN_OFFSETS is a stage-B activation with act_period = 3 * deform_groups");
+    {   // act_vec implements NONE / RELU / LeakyReLU(0.1) / SiLU only: refuse the codes it would silently compute as LeakyReLU(0.1)
+        auto plain = [](int c) { return c == FLAIR_ACT_NONE || c == FLAIR_ACT_RELU || c == FLAIR_ACT_LRELU01 || c == FLAIR_ACT_SILU; };
+        FLAIR_CHECK(plain(p->actA) && (plain(p->actB) || p->actB == FLAIR_ACT_DCN_OFFSETS),
+                    "flair_conv_chain: activation codes (%d, %d) unsupported: NONE / RELU / LRELU01 / SILU (+ DCN_OFFSETS for stage B)",
+                    p->actA, p->actB);
+    }
     a.y = y; a.yLd = p->y_ld;
     a.T = p->T; a.H = p->H; a.W = p->W;
     a.dbg = nullptr;

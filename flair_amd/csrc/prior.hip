@@ -164,6 +164,7 @@ __global__ __launch_bounds__(256) void argmax_codebook_kernel(const E* logits, i
     int best = 0;
     if (forced) {
         best = forced[row];
+        best = best < 0 ? 0 : (best >= N ? N - 1 : best);   // an out-of-range code index must not read outside the codebook
     } else {
         float bv = -INFINITY;
         best = N;

@@ -453,15 +453,16 @@ class UNet(nn.Module):
             fn = self._forward_clip_graphed if (self.use_hip_graph and getattr(self, "_trace", None) is None) \
                 else self._forward_clip
             outs.append(fn(x[b * T:(b + 1) * T].float().contiguous(), timesteps[b * T:(b + 1) * T].float().contiguous(),
-                           low_res_input[b].float().contiguous(), rnn_input[b].float(), enable_cross_frames, vw))
+                           low_res_input[b].float().contiguous(), rnn_input[b].float(), enable_cross_frames, vw,
+                           **({"clip": b} if fn == self._forward_clip_graphed else {})))
         return outs[0] if B == 1 else torch.cat(outs, dim=0)
 
-    def _forward_clip_graphed(self, x, level, low_res, rnn, enable_cross_frames, vsrpp_weights):
+    def _forward_clip_graphed(self, x, level, low_res, rnn, enable_cross_frames, vsrpp_weights, clip=0):
         """One hipGraph per (clip shape, dtype, weight-map kind); re-captured when the conditioning (low-res clip, flow
         source, per-pixel weight map) or the sampler's chain counter changes -- same scheme as unet_new.UNetModel."""
         vw_t = vsrpp_weights if isinstance(vsrpp_weights, torch.Tensor) else None
         key = (tuple(x.shape), self.dtype, bool(enable_cross_frames),
-               tuple(vw_t.shape) if vw_t is not None else vsrpp_weights, x.device)
+               tuple(vw_t.shape) if vw_t is not None else vsrpp_weights, x.device, clip)
         src = (rnn.data_ptr(), rnn._version, low_res.data_ptr(), low_res._version, getattr(self, "_flow_gen", 0),
                (vw_t.data_ptr(), vw_t._version) if vw_t is not None else None)
         ent = self._graphs.get(key)
@@ -482,7 +483,7 @@ class UNet(nn.Module):
             cur.wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):   # see unet_new.UNetModel
                 out = self._forward_clip(st["x"], st["level"], st["lr"], st["rnn"], enable_cross_frames, st["vw"],
                                          flows=flows)
             ent = dict(graph=graph, st=st, out=out, src=src, flows=flows)

@@ -801,11 +801,14 @@ class UNetModel(nn.Module):
             fn = self._forward_clip_graphed if (self.use_hip_graph and not isinstance(vw, torch.Tensor)
                                                 and getattr(self, "_trace", None) is None) else self._forward_clip
             outs.append(fn(x[b * T:(b + 1) * T].float().contiguous(), timesteps[b * T:(b + 1) * T],
-                           low_res_input[b].float(), rnn_input[b].float(), enable_cross_frames, vw))
+                           low_res_input[b].float(), rnn_input[b].float(), enable_cross_frames, vw,
+                           **({"clip": b} if fn == self._forward_clip_graphed else {})))
         return outs[0] if B == 1 else torch.cat(outs, dim=0)
 
-    def _forward_clip_graphed(self, x, t, low_res, rnn, enable_cross_frames, vsrpp_weights):
-        key = (tuple(x.shape), self.dtype, bool(enable_cross_frames), vsrpp_weights, x.device)
+    def _forward_clip_graphed(self, x, t, low_res, rnn, enable_cross_frames, vsrpp_weights, clip=0):
+        # one graph per clip of the batch: clips differ in their conditioning (rnn / low_res storage), so sharing one
+        # entry would evict and re-capture it on every forward of every sampler step
+        key = (tuple(x.shape), self.dtype, bool(enable_cross_frames), vsrpp_weights, x.device, clip)
         ent = self._graphs.get(key)
         # conditioning identity: storage + torch version + the sampler's chain counter (kernels launched
         # through ctypes do not bump _version, so every new chain refreshes conditioning and flows once)
@@ -827,7 +830,9 @@ class UNetModel(nn.Module):
             cur.wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # thread_local: HIP calls of OTHER host threads (flair_amd.io's reader pins memory / uploads the next
+            # window, its writer waits on events) must not invalidate this thread's capture
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 out = self._forward_clip(st["x"], st["t"], st["lr"], st["rnn"], enable_cross_frames,
                                          vsrpp_weights, flows=flows)
             ent = dict(graph=graph, st=st, out=out, src=src, flows=flows)

@@ -151,7 +151,9 @@ def iter_windows(paths, device, length=video.FRAME_SLICE_LEN, overlap=video.OVER
             raise item
         idx, u8, ev, _keep = item
         if ev is not None:
-            torch.cuda.current_stream(device).wait_event(ev)
+            cur = torch.cuda.current_stream(device)
+            cur.wait_event(ev)
+            u8.record_stream(cur)        # allocated on the side stream, read here: keep the block until this read is done
         yield idx, (u8.float() / 255.0).unsqueeze(0)
 
 

@@ -130,8 +130,11 @@ def conv(xs, weight, bias, cout, kernel, *, out=None, act=ACT_NONE, res0=None, r
     e0 = _prof_begin()
     wsb = _conv_ws_bytes(p)
     ws = _workspace(wsb, x0.device, "conv") if wsb else None
-    check(lib().flair_conv_nhwc(ctypes.byref(p), arr, ptr(weight), ptr(_f32(bias)), ptr(frame_bias), ptr(res0),
-                                ptr(res1), ptr(out), ptr(ws), ctypes.c_size_t(wsb), stream()), "flair_conv_nhwc")
+
+    def launch(_keep=xs):       # the segment tensors reach the library as raw pointers: keep them alive with the closure
+        check(lib().flair_conv_nhwc(ctypes.byref(p), arr, ptr(weight), ptr(_f32(bias)), ptr(frame_bias), ptr(res0),
+                                    ptr(res1), ptr(out), ptr(ws), ctypes.c_size_t(wsb), stream()), "flair_conv_nhwc")
+    launch()
     if e0 is not None:
         cin = sum(x.shape[3] for x in xs)
         taps = kernel[0] * kernel[1] * kernel[2]
@@ -139,7 +142,9 @@ def conv(xs, weight, bias, cout, kernel, *, out=None, act=ACT_NONE, res0=None, r
         flops = 2.0 * T * Ho * Wo * cout * cin * taps
         nbytes = esz * (cin * T * H * W + cout * T * Ho * Wo * (1 + (res0 is not None) + (res1 is not None))
                         + cout * taps * cin)
-        _prof_end(e0, ("conv", lib().flair_conv_variant(ctypes.byref(p))), x0.dtype, flops, nbytes)
+        _prof_end(e0, ("conv", lib().flair_conv_variant(ctypes.byref(p))), x0.dtype, flops, nbytes, launch,
+                  ("conv", T, H, W, tuple(x.shape[3] for x in xs), cout, tuple(kernel), stride, act,
+                   res0 is not None, res1 is not None, frame_bias is not None))
     return out
 
 
@@ -157,10 +162,12 @@ def _prof_begin():
     return e0
 
 
-def _prof_end(e0, family, dtype, flops, nbytes):
+def _prof_end(e0, family, dtype, flops, nbytes, replay=None, sig=None):
+    """replay: closure that re-issues the identical library call (its arguments stay alive with it), so that bench.py can
+    time every distinct launch shape by hipGraph replay of back-to-back launches; sig: hashable shape signature."""
     e1 = torch.cuda.Event(enable_timing=True)
     e1.record()
-    PROFILE.append((family, str(dtype), float(flops), float(nbytes), e0, e1))
+    PROFILE.append((family, str(dtype), float(flops), float(nbytes), e0, e1, replay, sig))
 
 
 def conv_variant(T, H, W, cins, cout, kernel, dtype=torch.bfloat16, stride=1):
@@ -261,8 +268,11 @@ def conv_chain(xs, wA, bA, actA, wB, bB, actB, c_mid, coutB, *, res0=None, res1=
     p.out_scale = out_scale
     assert wB.dtype == x0.dtype and wB.is_contiguous() and (wA is None or (wA.dtype == x0.dtype and wA.is_contiguous()))
     e0 = _prof_begin()
-    check(lib().flair_conv_chain(ctypes.byref(p), arr, ptr(wA), ptr(_f32(bA)), ptr(wB), ptr(_f32(bB)), ptr(res0),
-                                 ptr(res1), ptr(out), stream()), "flair_conv_chain")
+
+    def launch(_keep=xs):
+        check(lib().flair_conv_chain(ctypes.byref(p), arr, ptr(wA), ptr(_f32(bA)), ptr(wB), ptr(_f32(bB)), ptr(res0),
+                                     ptr(res1), ptr(out), stream()), "flair_conv_chain")
+    launch()
     if e0 is not None:
         cin = sum(x.shape[3] for x in xs)
         esz = x0.element_size()
@@ -270,7 +280,9 @@ def conv_chain(xs, wA, bA, actA, wB, bB, actB, c_mid, coutB, *, res0=None, res1=
         flops = 2.0 * 9 * px * (c_mid * coutB + (cin * c_mid if wA is not None else 0))
         nbytes = esz * (px * (cin + coutB * (1 + (res0 is not None) + (res1 is not None)))
                         + 9 * c_mid * coutB + (9 * cin * c_mid if wA is not None else 0))
-        _prof_end(e0, ("chain", 2 if wA is not None else 1, c_mid), x0.dtype, flops, nbytes)
+        _prof_end(e0, ("chain", 2 if wA is not None else 1, c_mid), x0.dtype, flops, nbytes, launch,
+                  ("chain", T, H, W, tuple(x.shape[3] for x in xs), c_mid, coutB, wA is not None, res0 is not None,
+                   res1 is not None))
     return out
 
 
@@ -318,13 +330,17 @@ def group_norm(x, gamma, beta, *, x1=None, groups=32, eps=1e-5, act=ACT_NONE, fi
         assert film.dtype == torch.float32 and film.stride(1) == 1 and film.shape[0] == T
     ws = _workspace(lib_ws_bytes(p), x.device)
     e0 = _prof_begin()
-    check(lib().flair_groupnorm_nhwc(ctypes.byref(p), ptr(x), ptr(x1), ptr(_f32(gamma)), ptr(_f32(beta)),
-                                     ptr(film), ptr(out), ptr(raw), ptr(ws), stream()),
-          "flair_groupnorm_nhwc")
+
+    def launch():
+        check(lib().flair_groupnorm_nhwc(ctypes.byref(p), ptr(x), ptr(x1), ptr(_f32(gamma)), ptr(_f32(beta)),
+                                         ptr(film), ptr(out), ptr(raw), ptr(ws), stream()),
+              "flair_groupnorm_nhwc")
+    launch()
     if e0 is not None:   # two-pass GroupNorm: the input is read twice, the output written once
         numel_in, numel_out = T * H * W * C, T * Ho * Wo * C
         _prof_end(e0, ("gn",), x.dtype, 8.0 * numel_in,
-                  x.element_size() * (2 * numel_in + numel_out * (2 if want_raw else 1)))
+                  x.element_size() * (2 * numel_in + numel_out * (2 if want_raw else 1)), launch,
+                  ("gn", T, H, W, C, c0, groups, p.frames_per_stat, act, resample, want_raw, film is not None))
     return (out, raw) if want_raw else out
 
 
@@ -394,10 +410,14 @@ def qkv_attention(qkv, heads, *, new_order=False, out=None):
         p.q_off, p.k_off, p.v_off, p.head_stride = 0, d, 2 * d, 3 * d
     p.scale = 1.0 / (d ** 0.5)
     e0 = _prof_begin()
-    check(lib().flair_qkv_attention(ctypes.byref(p), ptr(qkv), ptr(out), stream()), "flair_qkv_attention")
+
+    def launch():
+        check(lib().flair_qkv_attention(ctypes.byref(p), ptr(qkv), ptr(out), stream()), "flair_qkv_attention")
+    launch()
     if e0 is not None:   # QK^T + AV: 4 * frames * heads * L^2 * d FLOPs; q, k, v read + out written
         L = H * W
-        _prof_end(e0, ("attn", L), qkv.dtype, 4.0 * F_ * heads * L * L * d, qkv.element_size() * 4.0 * F_ * L * C)
+        _prof_end(e0, ("attn", L), qkv.dtype, 4.0 * F_ * heads * L * L * d, qkv.element_size() * 4.0 * F_ * L * C,
+                  launch, ("attn", F_, L, heads, d, new_order))
     return out
 
 
@@ -486,12 +506,16 @@ def dcn_align(x0, x1, raw, flow1, flow2, weight, bias, cout, *, groups=16, max_m
     p.max_residue_magnitude = max_mag
     p.raw_activated = int(raw_activated)
     e0 = _prof_begin()
-    check(lib().flair_dcn_align(ctypes.byref(p), ptr(x0), ptr(x1), ptr(raw), ptr(flow1), ptr(flow2), ptr(weight),
-                                ptr(_f32(bias)), ptr(out), stream()), "flair_dcn_align")
+
+    def launch():
+        check(lib().flair_dcn_align(ctypes.byref(p), ptr(x0), ptr(x1), ptr(raw), ptr(flow1), ptr(flow2), ptr(weight),
+                                    ptr(_f32(bias)), ptr(out), stream()), "flair_dcn_align")
+    launch()
     if e0 is not None:   # bytes = esz*(2c + 27G + c)*H*W; FLOPs = 2*9*2c*c*H*W + 9*2c*H*W*8
         px = F_ * H * W
         _prof_end(e0, ("dcn", cout), x0.dtype, px * (2.0 * 9 * 2 * ch * cout + 9.0 * 2 * ch * 8),
-                  x0.element_size() * px * (2 * ch + 27 * groups + cout))
+                  x0.element_size() * px * (2 * ch + 27 * groups + cout), launch,
+                  ("dcn", F_, H, W, ch, cout, groups, flow2 is not None))
     return out
 
 
@@ -635,14 +659,18 @@ def vsrpp_prep(prop, feat2, flow1, flow_prev, cond1, cond2, flow2_out, flowpad):
     _, H, W, C = prop.shape
     second = flow_prev is not None
     e0 = _prof_begin()
-    check(lib().flair_vsrpp_prep(ptr(prop), _ld(prop), ptr(feat2 if second else None),
-                                 _ld(feat2) if second else 0, ptr(_f32(flow1)), ptr(_f32(flow_prev)),
-                                 dtype_code(prop), H, W, C, ptr(cond1), _ld(cond1), ptr(cond2 if second else None),
-                                 _ld(cond2) if second else 0, ptr(flow2_out if second else None), ptr(flowpad),
-                                 _ld(flowpad), stream()), "flair_vsrpp_prep")
+
+    def launch():
+        check(lib().flair_vsrpp_prep(ptr(prop), _ld(prop), ptr(feat2 if second else None),
+                                     _ld(feat2) if second else 0, ptr(_f32(flow1)), ptr(_f32(flow_prev)),
+                                     dtype_code(prop), H, W, C, ptr(cond1), _ld(cond1), ptr(cond2 if second else None),
+                                     _ld(cond2) if second else 0, ptr(flow2_out if second else None), ptr(flowpad),
+                                     _ld(flowpad), stream()), "flair_vsrpp_prep")
+    launch()
     if e0 is not None:   # reads 1-2 features, writes 1-2 warped features + the 4-channel flow pad
         n = 2 if second else 1
-        _prof_end(e0, ("prep",), prop.dtype, 0.0, prop.element_size() * H * W * (2.0 * n * C + flowpad.shape[3]) + 8.0 * H * W * n)
+        _prof_end(e0, ("prep",), prop.dtype, 0.0, prop.element_size() * H * W * (2.0 * n * C + flowpad.shape[3]) + 8.0 * H * W * n,
+                  launch, ("prep", H, W, C, second))
 
 
 def vsrpp_warp2(prop, feat2, flow1, flow2, cond1, cond2):
@@ -650,13 +678,17 @@ def vsrpp_warp2(prop, feat2, flow1, flow2, cond1, cond2):
     _, H, W, C = prop.shape
     second = flow2 is not None
     e0 = _prof_begin()
-    check(lib().flair_vsrpp_warp2(ptr(prop), _ld(prop), ptr(feat2 if second else None), _ld(feat2) if second else 0,
-                                  ptr(_f32(flow1)), ptr(_f32(flow2) if second else None), dtype_code(prop), H, W, C,
-                                  ptr(cond1), _ld(cond1), ptr(cond2 if second else None), _ld(cond2) if second else 0,
-                                  stream()), "flair_vsrpp_warp2")
+
+    def launch():
+        check(lib().flair_vsrpp_warp2(ptr(prop), _ld(prop), ptr(feat2 if second else None), _ld(feat2) if second else 0,
+                                      ptr(_f32(flow1)), ptr(_f32(flow2) if second else None), dtype_code(prop), H, W, C,
+                                      ptr(cond1), _ld(cond1), ptr(cond2 if second else None), _ld(cond2) if second else 0,
+                                      stream()), "flair_vsrpp_warp2")
+    launch()
     if e0 is not None:
         n = 2 if second else 1
-        _prof_end(e0, ("prep",), prop.dtype, 0.0, prop.element_size() * H * W * 2.0 * n * C + 8.0 * H * W * n)
+        _prof_end(e0, ("prep",), prop.dtype, 0.0, prop.element_size() * H * W * 2.0 * n * C + 8.0 * H * W * n,
+                  launch, ("warp2", H, W, C, second))
 
 
 def gated_blend(x, m, gate, out=None):

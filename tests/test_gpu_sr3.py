@@ -130,14 +130,20 @@ def test_sr3_hip_graph_replay_matches_eager(dev, tensor_weights):
     T, S = 4, 64
     g = torch.Generator().manual_seed(2)
     wmap = (0.9 + 0.1 * torch.rand(1, T, 1, S, S, generator=g)).to(dev) if tensor_weights else 0.93
-    cases = []
-    for seed, lvl in [(5, 0.83), (5, 0.31), (9, 0.97)]:        # same clip twice, then a new clip
+    cases, clips = [], {}
+    for seed, lvl in [(5, 0.83), (5, 0.31), (5, 0.55), (9, 0.97)]:   # the same clip three times, then a new clip
         x, lr, level = inputs(T, S, seed=seed)
-        cases.append(((x + lvl).to(dev), lr.to(dev), torch.full((T,), lvl).to(dev)))
+        if seed not in clips:
+            clips[seed] = lr.to(dev)                           # ONE device tensor per clip: later calls are pure replays
+        cases.append(((x + lvl).to(dev), clips[seed], torch.full((T,), lvl).to(dev)))
     eager = [m(x, lv, low_res_input=lr, num_frames=T, vsrpp_weights=wmap).clone() for x, lr, lv in cases]
     m.enable_hip_graph()
+    graphs = []
     for (x, lr, lv), ref in zip(cases, eager):
         y = m(x, lv, low_res_input=lr, num_frames=T, vsrpp_weights=wmap)
         torch.cuda.synchronize()
         assert torch.equal(y, ref)
+        assert len(m._graphs) == 1
+        graphs.append(next(iter(m._graphs.values()))["graph"])
+    assert graphs[0] is graphs[1] is graphs[2] and graphs[3] is not graphs[0]   # replays with new x / level, then a re-capture
     m.enable_hip_graph(False)

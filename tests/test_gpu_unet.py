@@ -119,17 +119,25 @@ def test_hip_graph_replay_matches_eager(dev):
     m = m.to(dev)
     m.convert_to_fp16()
     T, S = 4, 32
-    cases = []
-    for seed, tval in [(3, 371), (3, 12), (8, 940)]:          # same clip twice, then a new clip
+    cases, clips = [], {}
+    for seed, tval in [(3, 371), (3, 12), (3, 655), (8, 940)]:   # the same clip three times, then a new clip
         x, lr, t = _inputs(T, S, seed=seed)
         x = x + 0.01 * tval                                    # a different latent every time
-        cases.append((x.to(dev), lr.to(dev), torch.full((T,), tval, dtype=torch.long, device=dev)))
+        if seed not in clips:
+            clips[seed] = lr.to(dev)                           # ONE device tensor per clip: later calls are pure replays
+        cases.append((x.to(dev), clips[seed], torch.full((T,), tval, dtype=torch.long, device=dev)))
     eager = [m(x, t, low_res_input=lr, num_frames=T, vsrpp_weights=1.0).clone() for x, lr, t in cases]
     m.enable_hip_graph()
+    graphs = []
     for (x, lr, t), ref in zip(cases, eager):
         y = m(x, t, low_res_input=lr, num_frames=T, vsrpp_weights=1.0)
         torch.cuda.synchronize()
         assert torch.equal(y, ref)
+        assert len(m._graphs) == 1
+        graphs.append(next(iter(m._graphs.values()))["graph"])
+    # calls 2 and 3 replayed the graph captured by call 1 with new x / t (nothing baked in at capture time);
+    # the new clip re-captured
+    assert graphs[0] is graphs[1] is graphs[2] and graphs[3] is not graphs[0]
     m.enable_hip_graph(False)
 
 

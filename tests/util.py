@@ -34,3 +34,18 @@ def assert_close(got, ref, dtype, what="", scale=1.0):
     bound = scale * rel * ref.abs().max().item() + ab
     assert err <= bound, f"{what}: max|err|={err:.3e} > {bound:.3e} (max|ref|={ref.abs().max().item():.3e})"
     return err
+
+
+def parity_log(line):
+    """Append one measured-error line to gpurun_out/r03_parity.txt (merged back from the GPU box; the copy under
+    profiles/ is the committed record).  Never fails a test."""
+    import os
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        d = os.path.join(root, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "r03_parity.txt"), "a") as f:
+            f.write(line.rstrip() + "\n")
+    except OSError:
+        pass
+    print(line)
