@@ -86,4 +86,8 @@ def test_bench_refuses_gpus_it_cannot_see():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=600)
-    assert r.returncode != 0 and "GPU(s) are visible" in (r.stderr + r.stdout)
+    # either the sysfs pre-check refuses (KFD topology readable), or -- no topology to read, as in a container without
+    # a GPU -- the spawned ranks fail and the launcher reports the failing rank instead of hanging or printing a line
+    text = r.stderr + r.stdout
+    assert r.returncode != 0 and ("GPU(s) are visible" in text or "exited with status" in text), text[-2000:]
+    assert '"metric"' not in r.stdout
