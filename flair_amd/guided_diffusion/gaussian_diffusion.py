@@ -231,10 +231,6 @@ class GaussianDiffusion:
         if tau is None:
             tau = 0
         if aux_model is not None and i <= start_timestep and i >= tau:
-            if not aligned:
-                raise NotImplementedError(
-                    "flair_amd: un-aligned face crop/paste (facelib, gaussian_diffusion.py:476-493) is "
-                    "outside the hot path; pass aligned=True")
             # NB: the reference evaluates the aux prior on the data-consistent x0; the fused
             # kernel applies consistency + blend in one pass, so materialise that x0 first.
             if restored is not None:
@@ -244,7 +240,24 @@ class GaussianDiffusion:
                 else:
                     x0c = ops.axpby(x0, restored, 1.0, -g)
                 x0, restored = x0c, None
-            aux = aux_model(x0, t, x).float().contiguous()
+            if not aligned:
+                # gaussian_diffusion.py:476-493: crop the faces out of x0 and x_t with the window's affine matrices, run
+                # the prior on the crops, warp its output back and paste it through the blurred parsing mask -- all on
+                # the GPU (flair_amd.guided_diffusion.face_restoration_helper; the reference goes through numpy / cv2)
+                if face_restore_helper is None or affine_matrices is None:
+                    raise ValueError("aligned=False needs face_restore_helper and affine_matrices "
+                                     "(gaussian_diffusion.py:476-483)")
+                aux_face = face_restore_helper.get_crop_face_from_affine_matrices(x0, affine_matrices)
+                aux_xt = face_restore_helper.get_crop_face_from_affine_matrices(x, affine_matrices)
+                aux_face = aux_model(aux_face, t, aux_xt)
+                inv_face, inv_mask = face_restore_helper.inverse_faces(aux_face, affine_matrices)
+                if tuple(inv_face.shape) != tuple(x0.shape):
+                    raise ValueError(f"inverse_faces returned {tuple(inv_face.shape)} for frames of {tuple(x0.shape)}: the "
+                                     "reference pastes at the face size (face_restoration_helper.py:318-323), so frames "
+                                     "must be face_size x face_size")
+                aux = ops.face_blend(x0, inv_face.float().contiguous(), inv_mask.float().contiguous())
+            else:
+                aux = aux_model(x0, t, x).float().contiguous()
         c = ops.SamplerCoefs()
         c.gamma = _scalar(gamma, 1.0)
         c.w_aux = _scalar(w, 0.5)

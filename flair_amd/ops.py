@@ -771,3 +771,40 @@ def sft_fuse(dec, scale, shift, w, out=None):
     check(lib().flair_sft_fuse(ptr(dec), ptr(scale), ptr(shift), ctypes.c_float(w), dtype_code(dec),
                                ctypes.c_long(dec.numel()), ptr(out), stream()), "flair_sft_fuse")
     return out
+
+
+# --------------------------------------------------------------------------- un-aligned prior branch (face crop / paste)
+def warp_affine_cubic(src, minv, out_hw, *, border=(0.0, 0.0, 0.0), pre=False, post=False):
+    """cv2.warpAffine(INTER_CUBIC, BORDER_CONSTANT) per image (flair_warp_affine_cubic).  src: (N,C,Hs,Ws) f32 or f64
+    (masks, C = 1); minv: (N, 6) float64 DEVICE tensor, the dst -> src matrices; -> (N,C,Hd,Wd) f32."""
+    N, C, Hs, Ws = src.shape
+    assert src.is_contiguous() and src.dtype in (torch.float32, torch.float64)
+    assert minv.dtype == torch.float64 and minv.is_contiguous() and tuple(minv.shape) == (N, 6) and minv.is_cuda
+    Hd, Wd = out_hw
+    out = torch.empty((N, C, Hd, Wd), dtype=torch.float32, device=src.device)
+    b = (ctypes.c_float * 4)(*([float(v) for v in border] + [0.0] * 4)[:4])
+    check(lib().flair_warp_affine_cubic(ptr(src), int(src.dtype == torch.float64), N, C, Hs, Ws, ptr(minv), Hd, Wd, b,
+                                        int(pre), int(post), ptr(out), stream()), "flair_warp_affine_cubic")
+    return out
+
+
+def face_mask_blur(parse_idx, N, H, W, lut, kern, *, repeats=2, edge=10, div=255.0):
+    """lut[parse_idx] -> repeats x separable float64 Gaussian blur (reflect-101) -> edge zeroed, / div
+    (flair_face_mask_blur).  parse_idx: (N*H*W,) int32; lut, kern: float64 DEVICE tensors -> (N,1,H,W) float64."""
+    assert parse_idx.dtype == torch.int32 and parse_idx.is_contiguous() and parse_idx.numel() == N * H * W
+    assert lut.dtype == torch.float64 and kern.dtype == torch.float64 and lut.is_cuda and kern.is_cuda
+    tmp = torch.empty((N, 1, H, W), dtype=torch.float64, device=parse_idx.device)
+    mask = torch.empty_like(tmp)
+    check(lib().flair_face_mask_blur(ptr(parse_idx), N, H, W, ptr(lut), lut.numel(), ptr(kern), kern.numel(), repeats, edge,
+                                     ctypes.c_double(div), ptr(tmp), ptr(mask), stream()), "flair_face_mask_blur")
+    return mask
+
+
+def face_blend(x0, face, mask):
+    """x0 * (1 - mask) + face * mask; mask (N,1,H,W) f32 broadcast over the channels."""
+    N, C, H, W = x0.shape
+    assert x0.dtype == face.dtype == mask.dtype == torch.float32 and x0.is_contiguous() and face.is_contiguous()
+    assert mask.is_contiguous() and tuple(mask.shape) == (N, 1, H, W) and face.shape == x0.shape
+    out = torch.empty_like(x0)
+    check(lib().flair_face_blend(ptr(x0), ptr(face), ptr(mask), N, C, H, W, ptr(out), stream()), "flair_face_blend")
+    return out

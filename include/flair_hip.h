@@ -395,6 +395,28 @@ int flair_adain_nhwc(const void* content, int c_ld, const void* style, int s_ld,
 int flair_sft_fuse(const void* dec, const void* scale, const void* shift, float w, int dtype, long n, void* y,
                    hipStream_t stream);
 
+/* ------------------------------------------------------------- un-aligned prior branch: face crop / inverse paste
+ * (second half; gaussian_diffusion.py:476-493 calls facelib/utils/face_restoration_helper.py:225-254
+ * and :264-335 every denoising step and round-trips the frames through numpy / OpenCV).  Images are the sampler's
+ * (N,C,H,W) f32 tensors; the affine matrices are an INPUT (computed once per window, scripts/video_sample.py:446-448).
+ * OpenCV's arithmetic is restated from its published algorithm (cv2 absent here: parity unpinned). */
+/* cv2.warpAffine(src, M, (Wd, Hd), flags=INTER_CUBIC, borderMode=BORDER_CONSTANT, borderValue=border) per image n.
+ * minv: DEVICE [N][6] doubles, the dst -> src matrix warpAffine derives from M (its inverse, computed in double on the
+ * host exactly as imgwarp.cpp does).  src: [N][C][Hs][Ws] f32, or f64 when src_is_f64 (masks).  border: HOST floats [C].
+ * pre = 1 applies clamp((x + 1) / 2, 0, 1) * 255 to every source sample (face_restoration_helper.py:230), post = 1 applies
+ * clamp((y / 255 - 0.5) / 0.5, -1, 1) to the result (:246-253); dst: [N][C][Hd][Wd] f32.  C <= 4. */
+int flair_warp_affine_cubic(const void* src, int src_is_f64, int N, int C, int Hs, int Ws, const double* minv,
+                            int Hd, int Wd, const float* border, int pre, int post, float* dst, hipStream_t stream);
+/* The paste mask of inverse_faces (face_restoration_helper.py:283-317): mask = lut[parse_idx] (MASK_COLORMAP, DEVICE
+ * doubles [nlut]), `repeats` x cv2.GaussianBlur(mask, (ksize, ksize), sigma) in float64 with BORDER_REFLECT_101 (kern:
+ * DEVICE doubles [ksize] = cv2.getGaussianKernel), the `edge` outermost pixels zeroed, / div.  parse_idx: [N][H][W]
+ * int32 (flair_argmax_codebook's idx); tmp, mask: [N][H][W] doubles (mask is the result). */
+int flair_face_mask_blur(const int* parse_idx, int N, int H, int W, const double* lut, int nlut, const double* kern,
+                         int ksize, int repeats, int edge, double div, double* tmp, double* mask, hipStream_t stream);
+/* x0 * (1 - mask) + face * mask (gaussian_diffusion.py:491); x0, face, out: [N][C][H][W] f32; mask: [N][1][H][W] f32. */
+int flair_face_blend(const float* x0, const float* face, const float* mask, int N, int C, int H, int W, float* out,
+                     hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

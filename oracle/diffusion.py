@@ -128,9 +128,11 @@ def consistency_gammas(tab, zeta, noise_level):
 def sample_loop(tab, model, x_T, *, model_kwargs, learned_range=True, restore_fn=None,
                 aux_model=None, w=0.5, tau=0, rho=0.35, noise_level=None, zeta=-1,
                 prev_recon=None, t_start=-1, step_noise=None, clip_denoised=True,
-                sr3_noise_level=False, trace=None):
-    """p_sample_loop_progressive + p_sample + p_mean_variance with ``aligned=True``
-    (gaussian_diffusion.py:250-342, 423-517, 589-689; model wrapping respace.py:155-167).
+                sr3_noise_level=False, trace=None, aligned=True, face_restore_helper=None, affine_matrices=None):
+    """p_sample_loop_progressive + p_sample + p_mean_variance (gaussian_diffusion.py:250-342, 423-517, 589-689; model
+    wrapping respace.py:155-167).  ``aligned=False`` takes the crop / paste branch of :476-493 through
+    ``face_restore_helper`` (an object with the reference helper's ``get_crop_face_from_affine_matrices`` and
+    ``inverse_faces``; tests pass one built on oracle/facewarp.py).
 
     ``step_noise``: list of per-iteration gaussian tensors replacing ``randn_like``
     (index 0 = first executed step), so CPU and GPU runs can share the draw.
@@ -168,7 +170,14 @@ def sample_loop(tab, model, x_T, *, model_kwargs, learned_range=True, restore_fn
             if clip_denoised:
                 x0 = x0.clamp(-1, 1)
         if aux_model is not None and i <= idx[0] and i >= tau:
-            face = aux_model(x0, t, img)
+            if aligned:
+                face = aux_model(x0, t, img)
+            else:
+                aux_face = face_restore_helper.get_crop_face_from_affine_matrices(x0, affine_matrices)
+                aux_xt = face_restore_helper.get_crop_face_from_affine_matrices(img, affine_matrices)
+                aux_face = aux_model(aux_face, t, aux_xt)
+                inv_face, inv_mask = face_restore_helper.inverse_faces(aux_face, affine_matrices)
+                face = x0 * (1 - inv_mask) + inv_face * inv_mask
             if clip_denoised:
                 face = face.clamp(-1, 1)
             wt = _at(ws, t, img)
