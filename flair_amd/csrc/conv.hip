@@ -59,6 +59,7 @@ struct ConvArgs {
     float actParam;        // FLAIR_ACT_DCN_OFFSETS: max residue magnitude
     int actPeriod;         // FLAIR_ACT_DCN_OFFSETS: 3 * deform groups
     int Hin, Win;          // input frame size (== H, W when stride == 1); H, W, P describe the OUTPUT
+    int esz;               // element size in bytes (2: bf16, 4: f32)
 };
 
 // Phase-timing switches of the halo kernel (how profiles/README.md's dissection was measured):
@@ -810,6 +811,367 @@ int launch_halo_ks(const ConvArgs& a0, hipStream_t s) {
     return FLAIR_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// Persistent LDS-DMA 3x3 (x KT) convolution (round 3; bf16; variant 8).
+//
+// What the counters said about conv3x3_halo_kernel<8> (profiles/r02z_conv_pmc_sq.txt): per K chunk a
+// workgroup moves 73 KB through the VGPRs into LDS (ds_write_b128: 13 cycles of register transfer per instruction), every
+// wave re-reads 1.5 fragments per MFMA, and each of the 4096 workgroups of a clip-level launch pays its own first-fetch
+// latency and epilogue with only one other workgroup per CU to hide them: 2 660 LDS cycles against 2 304 MFMA cycles per
+// chunk, 0.30 of the matrix peak.  This kernel changes all three:
+//   * staging is `buffer_load_dwordx4 ... lds` (LDS-DMA): no VGPR round trip, no ds_write; the LDS image is 64-byte rows
+//     (one pixel / one (tap, cout) of a 32-channel chunk) written linearly by the DMA, with the 16-byte chunk XOR-swizzled
+//     on the SOURCE address (pixel rows by (column >> 2) & 3, weight rows by (cout >> 2) & 3) so that every ds_read_b128
+//     fragment read is conflict-free (16 lanes of a read group always cover 16 distinct 16-byte slots);
+//   * a wave owns TWO image rows x 32 pixels x 64 couts (four 32x32 accumulators): for one column tap kw the four halo
+//     rows it touches are read once and serve all three row taps: 20 fragment reads per 24 MFMAs (0.83 instead of 1.5);
+//   * workgroups are persistent: 8 waves = a 16-row x 32-pixel x 64-cout tile per step, one workgroup per CU walking its
+//     share of the tiles; the (tile, chunk) sequence is one software pipeline -- chunk n+1 (of this tile or the next) is in
+//     flight by DMA into the other LDS stage while chunk n is multiplied, so first-fetch latency and the epilogue stores of
+//     a tile hide behind the neighbouring tiles' matrix work.  One barrier per chunk.
+// Tiles are dealt so that the workgroups of one XCD (blockIdx & 7) work on neighbouring tiles of one frame at the same
+// time (shared halo lines and weights hit in that XCD's L2).  Epilogue straight from the accumulators (v_permlane32_swap
+// pairs give each lane 8 consecutive couts of its pixel: 16-byte stores / residual loads).
+// Needs bf16, stride 1, 3x3 spatial taps, W % 32 == 0, H % 16 == 0, Cout % 8 == 0.
+struct DmaTile {
+    int t, h0, w0, co0;
+};
+
+// One LDS-DMA wave instruction: 64 lanes x 16 bytes from `desc` (buffer descriptor words in SGPRs) at per-lane byte
+// offset `voff` (out-of-range offsets deliver zeros) to LDS bytes [ldsAddr, ldsAddr + 1024).  Inline asm so that hipcc
+// neither counts it in its own vmcnt bookkeeping nor waits for it ahead of unrelated ds_reads (it drains every LDS-DMA
+// before the next LDS read it cannot tell apart from the DMA's target; cdna_hip_programming.md section 5, trap (a)): the
+// kernel waits with its own `s_waitcnt vmcnt(0)` before the barrier that publishes a stage.  M0 is saved and restored.
+__device__ __forceinline__ void dma16(u32x4_t desc, unsigned voff, unsigned ldsAddr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(ldsAddr), "s"(desc)
+                 : "memory");
+}
+
+__device__ __forceinline__ u32x4_t make_desc(const void* base, unsigned bytes) {
+    const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+    u32x4_t d;
+    d.x = __builtin_amdgcn_readfirstlane((unsigned)b);
+    d.y = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32) & 0xffffu);
+    d.z = __builtin_amdgcn_readfirstlane(bytes);
+    d.w = 0x00020000u;
+    return d;
+}
+
+template <int DUMMY>
+__global__ __launch_bounds__(512, 2) void conv3x3_dma_kernel(ConvArgs a, int nTiles, int tilesPerXcd) {
+    using E = bf16_t;
+    constexpr int TH = 16, HWP = 34;                       // tile rows, halo pitch in pixels
+    constexpr int HALO_ROWS = (TH + 2) * HWP;              // 612 staged pixels
+    constexpr int HALO_INSTR = (HALO_ROWS + 15) / 16;      // 39 DMA wave-instructions of 16 rows x 64 B
+    constexpr int W_INSTR = 64 * 9 / 16;                   // 36
+    constexpr int HALO_BYTES = HALO_INSTR * 1024;          // 39 936
+    constexpr int STAGE_BYTES = HALO_BYTES + W_INSTR * 1024;   // 76 800
+    constexpr int NSLOT = (HALO_INSTR + W_INSTR + 7) / 8;  // DMA instructions per wave and chunk (10)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int taps = a.KT * 9, pt = a.KT / 2;
+    const int chunksPerTap = a.CinTot / 32;
+    const int H = a.H, W = a.W, T = a.T;
+
+    // ---- this workgroup's tiles: XCD x (= blockIdx & 7) owns the list entries [x * tilesPerXcd, (x + 1) * tilesPerXcd),
+    // its workgroups (slot = blockIdx >> 3) take entries slot, slot + slotsPerXcd, ...
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slotsPerXcd = gridDim.x >> 3;
+    const int tilesW = W / 32, tilesH = H / TH, nCoTiles = a.nCoTiles;
+    auto tile_at = [&](int i, DmaTile& tl) -> bool {       // i-th tile of this workgroup
+        const int inXcd = slot + i * slotsPerXcd;
+        const int id = xcd * tilesPerXcd + inXcd;
+        if (inXcd >= tilesPerXcd || id >= nTiles) return false;
+        int rest = id;
+        tl.co0 = (rest % nCoTiles) * 64;
+        rest /= nCoTiles;
+        tl.w0 = (rest % tilesW) * 32;
+        rest /= tilesW;
+        tl.h0 = (rest % tilesH) * TH;
+        tl.t = rest / tilesH;
+        return true;
+    };
+
+    // ---- DMA slots of this wave: instruction ids wave * NSLOT + i over [halo instructions | weight instructions | idle].
+    // Lane l of an instruction fills LDS row 16 * id + (l >> 2), physical 16-byte chunk l & 3, with LOGICAL chunk
+    // (l & 3) ^ swz(row) of that row's pixel / weight row.  Idle slots and out-of-image pixels use an out-of-range offset
+    // (the DMA writes zeros: zero padding for free, no branches).
+    const int lrow = lane >> 2, lchunk = lane & 3;
+    unsigned hpix[NSLOT];          // halo slots: pixel index inside the frame (0xffffffff: outside); weight slots: unused
+    unsigned woff[NSLOT];          // weight slots: byte offset of the lane's row / chunk inside the packed weights
+    unsigned hchunk[NSLOT];        // halo slots: 16 * logical chunk
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i) {
+        const int id = wave * NSLOT + i;
+        const int c = (id * 16 + lrow) % HWP;
+        hchunk[i] = (unsigned)((lchunk ^ ((c >> 2) & 3)) << 4);
+    }
+    auto setup_tile = [&](const DmaTile& tl) {
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) {
+            const int id = wave * NSLOT + i;
+            const int R = id * 16 + lrow;
+            const int hr = R / HWP, c = R - hr * HWP;
+            const int hh = tl.h0 - 1 + hr, ww = tl.w0 - 1 + c;
+            const bool okh = R < HALO_ROWS && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
+            hpix[i] = okh ? (unsigned)(hh * W + ww) : 0xffffffffu;
+            const int row = R - HALO_INSTR * 16;               // tap9 * 64 + co (weight slots)
+            const int tap9 = row >> 6, co = row & 63;
+            const bool okw = row >= 0 && row < 576 && tl.co0 + co < a.Cout;
+            woff[i] = okw ? (unsigned)(((tl.co0 + co) * taps + tap9) * a.CinTot) * 2u + ((lchunk ^ ((co >> 2) & 3)) << 4) : FLAIR_OOB;
+        }
+    };
+
+    const u32x4_t wdesc = make_desc(a.w, a.wBytes);
+    // K walk state of the ISSUE side (block uniform)
+    struct Walk {
+        int dt, seg, cb, segOff;
+    };
+    auto walk_first = [&](int t, Walk& wk) {
+        wk.dt = -pt; wk.seg = 0; wk.cb = 0; wk.segOff = 0;
+        while (wk.dt <= pt && (unsigned)(t + wk.dt) >= (unsigned)T) ++wk.dt;
+    };
+    auto walk_next = [&](int t, Walk& wk) {
+        ++wk.cb;
+        if (wk.cb * 32 >= a.segC[wk.seg]) {
+            wk.cb = 0;
+            wk.segOff += a.segC[wk.seg];
+            if (++wk.seg >= a.nseg) {
+                wk.seg = 0;
+                wk.segOff = 0;
+                ++wk.dt;
+                while (wk.dt <= pt && (unsigned)(t + wk.dt) >= (unsigned)T) ++wk.dt;
+            }
+        }
+    };
+    auto chunks_of = [&](int t) {
+        int n = 0;
+        for (int d = -pt; d <= pt; ++d) n += (unsigned)(t + d) < (unsigned)T ? 1 : 0;
+        return n * chunksPerTap;
+    };
+    auto issue = [&](const DmaTile& tl, const Walk& wk, int stage) {
+        const unsigned ld = (unsigned)a.segLd[wk.seg] * 2u;
+        const char* frame = reinterpret_cast<const char*>(a.x[wk.seg]) + (size_t)(tl.t + wk.dt) * H * W * ld;
+        const u32x4_t xdesc = make_desc(frame, a.segBytes[wk.seg]);      // one input frame
+        const unsigned cofs = (unsigned)(wk.cb * 64);
+        const unsigned kofs = (unsigned)((wk.dt + pt) * 9 * a.CinTot + wk.segOff + wk.cb * 32) * 2u;
+        const unsigned sbase = (unsigned)(stage * STAGE_BYTES + wave * NSLOT * 1024);
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) {
+            const bool isw = wave * NSLOT + i >= HALO_INSTR;        // wave-uniform
+            const unsigned offh = hpix[i] == 0xffffffffu ? FLAIR_OOB : hpix[i] * ld + cofs + hchunk[i];
+            const unsigned offw = woff[i] == FLAIR_OOB ? FLAIR_OOB : woff[i] + kofs;
+            u32x4_t d;
+            d.x = isw ? wdesc.x : xdesc.x;
+            d.y = isw ? wdesc.y : xdesc.y;
+            d.z = isw ? wdesc.z : xdesc.z;
+            d.w = 0x00020000u;
+            // instruction ids past the last weight row (wave 7's tail slots) write their zeros to a scratch area behind the
+            // two stages instead of the first bytes of the next stage
+            const bool idle = wave * NSLOT + i >= HALO_INSTR + W_INSTR;
+            dma16(d, isw ? offw : offh, idle ? (unsigned)(2 * STAGE_BYTES + (wave * NSLOT + i - HALO_INSTR - W_INSTR) * 1024) : sbase + i * 1024);
+        }
+    };
+
+    // ---- fragment read offsets (per lane, fixed).  A: weight row tap9 * 64 + cf * 32 + lr, chunk 2 s + lh;
+    // B: halo row (2 wave + j + kh) * 34 + kw + lr, same chunk; XOR terms as written by the DMA.
+    unsigned aoff[2], boff[3][2];
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+        aoff[s_] = (unsigned)(HALO_BYTES + lr * 64 + (((2 * s_ + lh) ^ ((lr >> 2) & 3)) << 4));
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+            boff[kw][s_] = (unsigned)((2 * wave * HWP + kw + lr) * 64 + (((2 * s_ + lh) ^ (((kw + lr) >> 2) & 3)) << 4));
+    }
+
+    f32x16 acc[2][2];              // [row j][cout fragment]
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+    };
+    // One chunk = 3 column taps x 3 row taps x 8 MFMAs.  Fragments of step n + 1 (A: 4 reads; B: 8 more reads when the
+    // column tap changes) are requested before the 8 MFMAs of step n are issued (two fragment sets).
+    auto compute = [&](int stage) {
+        const char* sb = smem + stage * STAGE_BYTES;
+        uint4 fb[2][4][2];         // [set][halo row 2 wave + h][k-step]
+        uint4 fa[2][2][2];         // [set][cout fragment][k-step]
+        auto load_b = [&](int set, int kw) {
+#pragma unroll
+            for (int h = 0; h < 4; ++h)
+#pragma unroll
+                for (int s_ = 0; s_ < 2; ++s_)
+                    fb[set][h][s_] = *reinterpret_cast<const uint4*>(sb + h * (HWP * 64) + boff[kw][s_]);
+        };
+        auto load_a = [&](int set, int kh, int kw) {
+#pragma unroll
+            for (int cf = 0; cf < 2; ++cf)
+#pragma unroll
+                for (int s_ = 0; s_ < 2; ++s_)
+                    fa[set][cf][s_] = *reinterpret_cast<const uint4*>(sb + (kh * 3 + kw) * 4096 + cf * 2048 + aoff[s_]);
+        };
+        load_b(0, 0);
+        load_a(0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+#pragma unroll
+        for (int step = 0; step < 9; ++step) {
+            const int kw = step / 3, kh = step % 3;
+            const int nkw = (step + 1) / 3, nkh = (step + 1) % 3;
+            if (step < 8) {
+                if (nkh == 0) load_b(nkw & 1, nkw);
+                load_a((step + 1) & 1, nkh, nkw);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int cf = 0; cf < 2; ++cf) Mma<E>::run(fa[step & 1][cf], fb[kw & 1][j + kh], acc[j][cf]);
+            if (step < 8) {
+                if (nkh == 0) __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+                else __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
+        }
+    };
+    auto epilogue = [&](const DmaTile& tl) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int h = tl.h0 + 2 * wave + j, w = tl.w0 + lr;
+            const long p = ((long)tl.t * H + h) * W + w;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int co = tl.co0 + i * 32 + 16 * jj + 8 * lh;
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const auto sw2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[j][i][8 * jj + e]),
+                                                                          __float_as_uint(acc[j][i][8 * jj + 4 + e]), false, false);
+                        v[e] = __uint_as_float(sw2[0]);
+                        v[4 + e] = __uint_as_float(sw2[1]);
+                    }
+                    if (co >= a.Cout) continue;
+                    if (a.bias) {
+                        const float4 b0 = *reinterpret_cast<const float4*>(a.bias + co);
+                        const float4 b1 = *reinterpret_cast<const float4*>(a.bias + co + 4);
+                        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+                        v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                    }
+                    if (a.fbias) {
+                        const float* fb_ = a.fbias + (long)tl.t * a.fbiasLd + co;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += fb_[e];
+                    }
+                    if (a.act == FLAIR_ACT_DCN_OFFSETS) {
+                        dcn_offset_act<8>(v, co, a.actParam, a.actPeriod);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], a.act);
+                    }
+                    if (a.res0) {
+                        float r[8];
+                        Vec16<E>::load(reinterpret_cast<const E*>(a.res0) + p * a.res0Ld + co, r);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += r[e];
+                    }
+                    if (a.res1) {
+                        float r[8];
+                        Vec16<E>::load(reinterpret_cast<const E*>(a.res1) + p * a.res1Ld + co, r);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += r[e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= a.outScale;
+                    Vec16<E>::store(reinterpret_cast<E*>(a.y) + p * a.yLd + co, v);
+                }
+            }
+        }
+    };
+
+    // ---- the (tile, chunk) pipeline.  `cur` is the tile being multiplied, `nxt` the tile whose chunks are being issued.
+    DmaTile cur, nxt;
+    int iCur = 0, iNxt = 0;
+    if (!tile_at(0, cur)) return;
+    nxt = cur;
+    Walk wk;
+    walk_first(nxt.t, wk);
+    setup_tile(nxt);
+    int remIssue = chunks_of(nxt.t);           // chunks of `nxt` not yet issued
+    int remCompute = remIssue;                 // chunks of `cur` not yet multiplied
+    bool more = true;                          // is there a chunk left to issue
+    int stage = 0;
+    issue(nxt, wk, 0);
+    walk_next(nxt.t, wk);
+    --remIssue;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    zero_acc();
+    while (true) {
+        // issue the next chunk (of this tile, or the first chunk of the next tile) into the other stage: every wave has
+        // passed the barrier that ended the last read of that stage
+        if (more && remIssue == 0) {
+            ++iNxt;
+            more = tile_at(iNxt, nxt);
+            if (more) {
+                walk_first(nxt.t, wk);
+                setup_tile(nxt);
+                remIssue = chunks_of(nxt.t);
+            }
+        }
+        if (more) {
+            issue(nxt, wk, stage ^ 1);
+            walk_next(nxt.t, wk);
+            --remIssue;
+        }
+        compute(stage);
+        if (--remCompute == 0) {
+            epilogue(cur);
+            ++iCur;
+            if (!tile_at(iCur, cur)) break;
+            remCompute = chunks_of(cur.t);
+            zero_acc();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces of the next stage have landed ...
+        __syncthreads();                                      // ... and so have everybody else's
+        stage ^= 1;
+    }
+}
+
+int launch_dma(const ConvArgs& a0, hipStream_t s) {
+    ConvArgs a = a0;
+    a.nCoTiles = cdiv(a.Cout, 64);
+    const int nTiles = a.T * (a.H / 16) * (a.W / 32) * a.nCoTiles;
+    static int nCu = 0;
+    if (!nCu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) nCu = prop.multiProcessorCount;
+        if (nCu <= 0) nCu = 256;
+    }
+    int grid = nTiles < nCu ? (nTiles + 7) / 8 * 8 : nCu / 8 * 8;      // a multiple of 8: every XCD gets the same number of slots
+    if (grid < 8) grid = 8;
+    const int tilesPerXcd = (nTiles + 7) / 8;
+    const size_t lds = 2 * 76800 + 5 * 1024;       // two stages + the idle DMA slots' scratch
+    static bool attr = false;
+    if (!attr) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_dma_kernel<0>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        FLAIR_CHECK(e == hipSuccess, "flair_conv_nhwc: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr = true;
+    }
+    hipLaunchKernelGGL(conv3x3_dma_kernel<0>, dim3(grid), dim3(512), lds, s, a, nTiles, tilesPerXcd);
+    FLAIR_LAUNCH_CHECK();
+    return FLAIR_OK;
+}
+
 // TC x TP block tile (couts x pixels), 4 waves arranged WC x WP.
 template <typename E, int TC, int TP, int WC, int WP>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
@@ -1073,6 +1435,9 @@ int choose_variant(const ConvArgs& a) {
         const long per = (long)a.T * (a.W / 32) * cdiv(a.Cout, 64);
         // single-round launches (<= one workgroup per CU): K-split kernel, twice the wavefronts
         const bool ks = a.Cout % 8 == 0;
+        // persistent LDS-DMA kernel (bf16): launches of more than one round of 8-row tiles whose 16-row tiles fill most CUs
+        static const bool useDma = !(getenv("FLAIR_CONV_DMA") && atoi(getenv("FLAIR_CONV_DMA")) == 0);
+        if (useDma && a.esz == 2 && ks && a.H % 16 == 0 && per * cdiv(a.H, 8) > 256 && per * (a.H / 16) >= 192) return 8;
         if (per * cdiv(a.H, 8) >= 256) return ks && per * cdiv(a.H, 8) <= 256 ? 6 : 3;
         if (per * cdiv(a.H, 4) >= 256) return ks && per * cdiv(a.H, 4) <= 256 ? 7 : 4;
         return 5;
@@ -1108,6 +1473,7 @@ int dispatch(const ConvArgs& a0, hipStream_t s) {
             return rpw2 ? launch_halo_ks<E, 8, 2, 2>(a, s) : launch_halo_ks<E, 8, 1, 2>(a, s);
         }
         case 7: return launch_halo_ks<E, 4, 1, 2>(a, s);   // (two rows per wave leave 4 waves per CU here: +3.5 ms/step)
+        case 8: return launch_dma(a, s);
         default: return launch_halo<E, 2, 1, 1>(a, s);
     }
 }
@@ -1127,6 +1493,7 @@ static void fill_geometry(ConvArgs& a, const flair_conv_params* p) {
     a.CinTot = 0;
     for (int i = 0; i < p->nseg && i < 4; ++i) a.CinTot += p->seg_c[i];
     const int esz = p->dtype == FLAIR_BF16 ? 2 : 4;
+    a.esz = esz;
     a.wBytes = (unsigned)((unsigned long long)p->Cout * p->KT * p->KH * p->KW * a.CinTot * esz);
 }
 
@@ -1202,7 +1569,7 @@ extern "C" int flair_conv_nhwc(const flair_conv_params* p, const void* const* x,
         ConvArgs g{};
         fill_geometry(g, p);
         a.stride = g.stride; a.Hin = g.Hin; a.Win = g.Win; a.T = g.T; a.H = g.H; a.W = g.W; a.P = g.P;
-        a.KT = g.KT; a.KH = g.KH; a.KW = g.KW; a.Cout = g.Cout;
+        a.KT = g.KT; a.KH = g.KH; a.KW = g.KW; a.Cout = g.Cout; a.esz = g.esz;
     }
     FLAIR_CHECK(a.stride == 1 || a.stride == 2, "flair_conv_nhwc: stride %d unsupported", p->stride);
     FLAIR_CHECK(!p->asym_pad || (a.stride == 2 && a.KH == a.KW && a.KT == 1 && p->H % 2 == 0 && p->W % 2 == 0),

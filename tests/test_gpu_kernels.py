@@ -45,6 +45,14 @@ def _ops():
     (4, 64, 64, [64], 128, (3, 3, 3), 0, 1),
     (1, 250, 256, [64], 64, (1, 3, 3), 3, 1),       # last row of tiles hangs over the image
     (1, 125, 128, [32], 128, (1, 3, 3), 0, 0),
+    # persistent LDS-DMA kernel (bf16; f32 takes the halo kernel): >= 192 tiles of 16 rows x 32 px x 64 couts --
+    # one tile per workgroup, 2 and 1.5 tiles per workgroup, three temporal taps with clip edges, 432 couts, 4 segments
+    (4, 128, 128, [64], 128, (1, 3, 3), 0, 1),
+    (8, 128, 128, [64], 128, (1, 3, 3), 3, 2),
+    (3, 256, 256, [32], 64, (1, 3, 3), 2, 0),
+    (6, 64, 128, [32, 32], 128, (3, 3, 3), 1, 1),
+    (1, 128, 128, [128], 432, (1, 3, 3), 0, 0),
+    (2, 128, 256, [64, 32, 64, 32], 64, (1, 3, 3), 2, 2),
     # deep-K convolutions on few pixels: 128 x 128 tiles with split-K (16x16 / 8x8 levels)
     (8, 16, 16, [256], 256, (3, 3, 3), 3, 1),
     (16, 8, 8, [256, 256], 384, (1, 3, 3), 0, 2),
@@ -131,15 +139,16 @@ def test_conv_chain(dev, dtype, case):
 
 
 def test_conv_cases_cover_every_kernel_variant():
-    """The geometries above dispatch to all 8 conv kernel variants (flair_conv_variant)."""
+    """The geometries above dispatch to all 9 conv kernel variants (flair_conv_variant)."""
     ops = _ops()
     geo = [(2, 16, 16, [64], 64, (1, 3, 3)), (16, 64, 64, [64], 64, (1, 3, 3)), (2, 128, 128, [64, 64], 64, (1, 3, 3)),
            (1, 64, 32, [128], 432, (1, 3, 3)), (1, 30, 32, [64, 64, 64, 32], 64, (1, 3, 3)),
            (16, 72, 64, [32], 64, (3, 3, 3)), (2, 136, 128, [64], 64, (1, 3, 3)),
            (1, 256, 256, [64, 32], 64, (1, 3, 3)), (4, 64, 64, [64], 128, (3, 3, 3)),
-           (16, 256, 256, [64], 64, (1, 1, 1)), (16, 128, 128, [128], 128, (1, 1, 1)), (16, 4, 4, [512], 512, (3, 3, 3))]
+           (16, 256, 256, [64], 64, (1, 1, 1)), (16, 128, 128, [128], 128, (1, 1, 1)), (16, 4, 4, [512], 512, (3, 3, 3)),
+           (4, 128, 128, [64], 128, (1, 3, 3)), (16, 264, 256, [64], 64, (1, 3, 3))]
     seen = {ops.conv_variant(T, H, W, segs, cout, k) for T, H, W, segs, cout, k in geo}
-    assert seen == set(range(8)), seen
+    assert seen == set(range(9)), seen
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

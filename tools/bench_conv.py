@@ -24,6 +24,8 @@ SHAPES = [
     ("L5 clip 512->512 3d", 16, 8, 8, [512], 512, (3, 3, 3)),
     ("L6 clip 512->512 3d", 16, 4, 4, [512], 512, (3, 3, 3)),
     ("L0 clip 1x1 128->64", 16, 256, 256, [64, 64], 64, (1, 1, 1)),
+    ("L1 clip 384->128 2d", 16, 128, 128, [128, 128, 128], 128, (1, 3, 3)),
+    ("L2 clip 128->128 2d", 16, 64, 64, [128], 128, (1, 3, 3)),
 ]
 
 
