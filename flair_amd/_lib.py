@@ -42,6 +42,9 @@ def lib():
     """The loaded library; raises FlairHipUnavailable if it has not been built."""
     global _lib
     if _lib is None:
+        global LIB_PATH
+        if os.environ.get("FLAIR_HIP_LIB"):        # diagnostic builds (make timing / make probe) only
+            LIB_PATH = os.environ["FLAIR_HIP_LIB"]
         if not os.path.exists(LIB_PATH):
             raise FlairHipUnavailable(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "

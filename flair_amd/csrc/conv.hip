@@ -1127,13 +1127,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_dma_kernel(ConvArgs a, int nTi
             }
         }
         if (more) {
-            issue(nxt, wk, stage ^ 1);
+            if (FLAIR_DBG(a) != 12) issue(nxt, wk, stage ^ 1);     // (timing switches: 11 no MFMA phase, 12 no DMA, 13 no epilogue)
             walk_next(nxt.t, wk);
             --remIssue;
         }
-        compute(stage);
+        if (FLAIR_DBG(a) != 11) compute(stage);
         if (--remCompute == 0) {
-            epilogue(cur);
+            if (FLAIR_DBG(a) != 13) epilogue(cur);
             ++iCur;
             if (!tile_at(iCur, cur)) break;
             remCompute = chunks_of(cur.t);
