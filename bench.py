@@ -37,11 +37,13 @@ HBM_PEAK_GBS = 8000.0
 CONV_ROCPROF = {0: "conv_igemm_kernel<{E}, 128, 128, 2, 2>", 1: "conv_igemm_kernel<{E}, 64, 128, 1, 4>",
                 2: "conv_igemm_kernel<{E}, 64, 64, 2, 2>", 3: "conv3x3_halo_kernel<{E}, 8, 1, 1>",
                 4: "conv3x3_halo_kernel<{E}, 4, 1, 1>", 5: "conv3x3_halo_kernel<{E}, 2, 1, 1>",
-                6: "conv3x3_halo_ks_kernel<{E}, 8, 1, 2>", 7: "conv3x3_halo_ks_kernel<{E}, 4, 1, 2>"}
+                6: "conv3x3_halo_ks_kernel<{E}, 8, 1, 2>", 7: "conv3x3_halo_ks_kernel<{E}, 4, 1, 2>",
+                8: "conv3x3_dma_kernel<8, 2>", 9: "conv3x3_dma_kernel<8, 1>", 10: "conv3x3_dma_kernel<4, 1>"}
 CONV_VARIANTS = {0: "conv_igemm_kernel<128co x 128px>", 1: "conv_igemm_kernel<64co x 128px>",
                  2: "conv_igemm_kernel<64co x 64px>", 3: "conv3x3_halo_kernel<8 rows>",
                  4: "conv3x3_halo_kernel<4 rows>", 5: "conv3x3_halo_kernel<2 rows>",
-                 6: "conv3x3_halo_ks_kernel<8 rows>", 7: "conv3x3_halo_ks_kernel<4 rows>"}
+                 6: "conv3x3_halo_ks_kernel<8 rows>", 7: "conv3x3_halo_ks_kernel<4 rows>",
+                 8: "conv3x3_dma_kernel<16 rows, persistent>", 9: "conv3x3_dma_kernel<8 rows>", 10: "conv3x3_dma_kernel<4 rows>"}
 
 
 def pmc_traffic_for(kernel_fmt, dkey):
@@ -473,9 +475,10 @@ def main():
                        algorithmic_MB_per_launch=by / n / 1e6)
         return ent
     fams = [
-        family(lambda f: f[0] == "conv" and f[1] in (6, 7), "mfma",
-               "per-frame 3x3 convs of the BasicVSR++ recurrence (conv3x3_halo_ks_kernel / fused chains)"),
-        family(lambda f: f[0] == "conv" and f[1] in (3, 4, 5), "mfma", "clip-level 3x3 / 3x3x3 convs + c->432 offset convs (conv3x3_halo_kernel)"),
+        family(lambda f: f[0] == "conv" and f[1] in (6, 7, 9, 10), "mfma",
+               "per-frame 3x3 convs of the BasicVSR++ recurrence (conv3x3_dma_kernel<8|4 rows> / conv3x3_halo_ks_kernel)"),
+        family(lambda f: f[0] == "conv" and f[1] in (3, 4, 5, 8), "mfma",
+               "clip-level 3x3 / 3x3x3 convs + c->432 offset convs (conv3x3_dma_kernel<16 rows> / conv3x3_halo_kernel)"),
         family(lambda f: f[0] == "conv" and f[1] in (0, 1, 2), "mfma", "1x1 / strided / small-spatial convs (conv_igemm_kernel)"),
         family(lambda f: f[0] == "chain", "mfma", "fused per-frame conv chains (conv_chain_kernel)"),
         family(lambda f: f[0] == "gn", "hbm", "GroupNorm+SiLU+FiLM(+resample): gn_partial/finalize/apply, bytes = esz*3*numel"),

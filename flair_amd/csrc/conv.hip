@@ -22,6 +22,8 @@
 // other LDS buffer afterwards (one barrier per step).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -589,6 +591,13 @@ __global__ __launch_bounds__(256 * TH / RPW / CF, (256 * TH / RPW / CF) / 256) v
     const int taps = a.KT * 9;
     const int pt = a.KT / 2;
 
+    // the bias values of this lane's epilogue piece (see the epilogue), requested before anything else
+    float biasv[VEC];
+    {
+        const int bco = co0 + (lane % (64 / VEC)) * VEC;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) biasv[e] = (a.bias && bco < a.Cout) ? a.bias[bco + e] : 0.f;
+    }
     uint4 hreg[HI], wreg[WI];
     int dt = -pt, seg = 0, cb = 0, segOff = 0;
     auto dt_valid = [&](int d) { return (unsigned)(t + d) < (unsigned)a.T; };
@@ -699,22 +708,47 @@ __global__ __launch_bounds__(256 * TH / RPW / CF, (256 * TH / RPW / CF) / 256) v
 
     // two-stage pipeline: chunk k is multiplied out of stage k&1 while chunk k+1 is written to the
     // other stage and chunk k+2 is in flight from L2 (one register set, one barrier per chunk)
+    // (timing switches of the diagnostic build: 21 no MFMA phase, 22 return before the epilogue, 23 no in-loop staging,
+    //  24 return at once)
+    if (FLAIR_DBG(a) == 24) return;
     issue();
     write_lds(0);
     if (nch > 1) issue();
     __syncthreads();
     for (int k = 0; k < nch; ++k) {
-        compute(k & 1);
+        if (FLAIR_DBG(a) != 21) compute(k & 1);
         if (k + 1 < nch) {
-            write_lds((k + 1) & 1);      // stage (k+1)&1 was last read before the previous barrier
-            if (k + 2 < nch) issue();
+            if (FLAIR_DBG(a) != 23) write_lds((k + 1) & 1);      // stage (k+1)&1 was last read before the previous barrier
+            if (k + 2 < nch && FLAIR_DBG(a) != 23) issue();
             __syncthreads();
         }
     }
+    if (FLAIR_DBG(a) == 22) return;
 
-    // ---- epilogue: sum the two k-halves in the f32 staging tile, then transposed, coalesced stores
+    // ---- epilogue: sum the two k-halves in the f32 staging tile, then transposed, coalesced stores.
+    // Each lane finishes the SAME 16-byte channel piece (ch = lane % CHUNKS) of different pixels in every pass, so its VEC
+    // bias values were requested at kernel entry (biasv) and the residual pieces are requested here, ahead of the three
+    // barriers of the k-half reduction: a per-frame launch has nothing else to hide those round trips behind (they were
+    // issued after the staging tile was read: ~1 us of exposed latency per launch, 1 264 launches per step).
     constexpr int FPITCH = 64 * 4 + 16;
     constexpr int CHUNKS = 64 / VEC;                         // 16-byte output pieces per pixel
+    constexpr int PARTS = NW / TH;                           // wavefronts sharing one output row
+    constexpr int NIT = 32 * CHUNKS / 64 / PARTS;            // passes per wave
+    const int orow = wave % TH, part = wave / TH;
+    const int h = h0 + orow;
+    const long prow = ((long)t * a.H + h) * a.W + w0;
+    const int ech = lane % CHUNKS;                           // this lane's piece in every pass
+    const int eco = co0 + ech * VEC;
+    const bool eok = h < a.H && eco < a.Cout;
+    uint4 r0v[NIT], r1v[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const int px = ((k * PARTS + part) * 64 + lane) / CHUNKS;
+        const long p = prow + px;
+        r0v[k] = r1v[k] = make_uint4(0u, 0u, 0u, 0u);
+        if (eok && a.res0) r0v[k] = *reinterpret_cast<const uint4*>(reinterpret_cast<const E*>(a.res0) + p * a.res0Ld + eco);
+        if (eok && a.res1) r1v[k] = *reinterpret_cast<const uint4*>(reinterpret_cast<const E*>(a.res1) + p * a.res1Ld + eco);
+    }
     __syncthreads();                                         // LDS is free: all fragment reads are done
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
@@ -739,57 +773,47 @@ __global__ __launch_bounds__(256 * TH / RPW / CF, (256 * TH / RPW / CF) / 256) v
         }
         __syncthreads();
     }
-    constexpr int PARTS = NW / TH;                           // wavefronts sharing one output row
-    const int orow = wave % TH, part = wave / TH;
-    const int h = h0 + orow;
-    if (h >= a.H) return;
+    if (!eok) return;
     const char* tile = smem + orow * 32 * FPITCH;
-    const long prow = ((long)t * a.H + h) * a.W + w0;
 #pragma unroll
-    for (int it0 = 0; it0 < 32 * CHUNKS / 64; it0 += PARTS) {
-        const int it = it0 + part;
-        const int id = it * 64 + lane;
-        const int px = id / CHUNKS, ch = id % CHUNKS;
-        const int co = co0 + ch * VEC;
-        if (co >= a.Cout) continue;
+    for (int k = 0; k < NIT; ++k) {
+        const int px = ((k * PARTS + part) * 64 + lane) / CHUNKS;
         const long p = prow + px;
         float v[VEC];
-        const float* src = reinterpret_cast<const float*>(tile + px * FPITCH) + ch * VEC;
+        const float* src = reinterpret_cast<const float*>(tile + px * FPITCH) + ech * VEC;
 #pragma unroll
         for (int e = 0; e < VEC; e += 4) {
             const float4 q = *reinterpret_cast<const float4*>(src + e);
             v[e] = q.x; v[e + 1] = q.y; v[e + 2] = q.z; v[e + 3] = q.w;
         }
-        if (a.bias) {
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) v[e] += a.bias[co + e];
-        }
+        for (int e = 0; e < VEC; ++e) v[e] += biasv[e];
         if (a.fbias) {
-            const float* fb = a.fbias + (long)t * a.fbiasLd + co;
+            const float* fb = a.fbias + (long)t * a.fbiasLd + eco;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) v[e] += fb[e];
         }
         if (a.act == FLAIR_ACT_DCN_OFFSETS) {
-            dcn_offset_act<VEC>(v, co, a.actParam, a.actPeriod);
+            dcn_offset_act<VEC>(v, eco, a.actParam, a.actPeriod);
         } else {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) v[e] = apply_act(v[e], a.act);
         }
         if (a.res0) {
             float r[VEC];
-            Vec16<E>::load(reinterpret_cast<const E*>(a.res0) + p * a.res0Ld + co, r);
+            Vec16<E>::load(reinterpret_cast<const E*>(&r0v[k]), r);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) v[e] += r[e];
         }
         if (a.res1) {
             float r[VEC];
-            Vec16<E>::load(reinterpret_cast<const E*>(a.res1) + p * a.res1Ld + co, r);
+            Vec16<E>::load(reinterpret_cast<const E*>(&r1v[k]), r);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) v[e] += r[e];
         }
 #pragma unroll
         for (int e = 0; e < VEC; ++e) v[e] *= a.outScale;
-        Vec16<E>::store(reinterpret_cast<E*>(a.y) + p * a.yLd + co, v);
+        Vec16<E>::store(reinterpret_cast<E*>(a.y) + p * a.yLd + eco, v);
     }
 }
 
@@ -860,16 +884,22 @@ __device__ __forceinline__ u32x4_t make_desc(const void* base, unsigned bytes) {
     return d;
 }
 
-template <int DUMMY>
-__global__ __launch_bounds__(512, 2) void conv3x3_dma_kernel(ConvArgs a, int nTiles, int tilesPerXcd) {
+// NW wavefronts per workgroup, RPW image rows per wavefront (tile = NW * RPW rows x 32 pixels x 64 couts):
+//   <8, 2> clip-level launches (the shape described above);
+//   <8, 1> / <4, 1> single-round launches of 256 tiles of 8 / 4 rows = the per-frame convolutions of the BasicVSR++
+//   recurrence at 256^2 (c = 64) and 128^2 (c = 128): one tile per workgroup, where the gain is the short prologue (DMA instead
+//   of load -> ds_write -> barrier) and the register epilogue (no LDS transposition, no k-half reduction barriers).
+template <int NW, int RPW>
+__global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(ConvArgs a, int nTiles, int tilesPerXcd) {
     using E = bf16_t;
-    constexpr int TH = 16, HWP = 34;                       // tile rows, halo pitch in pixels
-    constexpr int HALO_ROWS = (TH + 2) * HWP;              // 612 staged pixels
-    constexpr int HALO_INSTR = (HALO_ROWS + 15) / 16;      // 39 DMA wave-instructions of 16 rows x 64 B
+    constexpr int TH = NW * RPW, HWP = 34;                 // tile rows, halo pitch in pixels
+    constexpr int HALO_ROWS = (TH + 2) * HWP;              // staged pixels
+    constexpr int HALO_INSTR = (HALO_ROWS + 15) / 16;      // DMA wave-instructions of 16 rows x 64 B
     constexpr int W_INSTR = 64 * 9 / 16;                   // 36
-    constexpr int HALO_BYTES = HALO_INSTR * 1024;          // 39 936
-    constexpr int STAGE_BYTES = HALO_BYTES + W_INSTR * 1024;   // 76 800
-    constexpr int NSLOT = (HALO_INSTR + W_INSTR + 7) / 8;  // DMA instructions per wave and chunk (10)
+    constexpr int HALO_BYTES = HALO_INSTR * 1024;
+    constexpr int STAGE_BYTES = HALO_BYTES + W_INSTR * 1024;
+    constexpr int NSLOT = (HALO_INSTR + W_INSTR + NW - 1) / NW;   // DMA instructions per wave and chunk
+    constexpr int BIAS_OFF = 2 * STAGE_BYTES + NW * 1024;  // two slots of 64 f32 biases (tile parity) behind the DMA scratch
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -974,7 +1004,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_dma_kernel(ConvArgs a, int nTi
             // instruction ids past the last weight row (wave 7's tail slots) write their zeros to a scratch area behind the
             // two stages instead of the first bytes of the next stage
             const bool idle = wave * NSLOT + i >= HALO_INSTR + W_INSTR;
-            dma16(d, isw ? offw : offh, idle ? (unsigned)(2 * STAGE_BYTES + (wave * NSLOT + i - HALO_INSTR - W_INSTR) * 1024) : sbase + i * 1024);
+            dma16(d, isw ? offw : offh, idle ? (unsigned)(2 * STAGE_BYTES + ((wave * NSLOT + i - HALO_INSTR - W_INSTR) % NW) * 1024) : sbase + i * 1024);
         }
     };
 
@@ -986,13 +1016,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_dma_kernel(ConvArgs a, int nTi
         aoff[s_] = (unsigned)(HALO_BYTES + lr * 64 + (((2 * s_ + lh) ^ ((lr >> 2) & 3)) << 4));
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw)
-            boff[kw][s_] = (unsigned)((2 * wave * HWP + kw + lr) * 64 + (((2 * s_ + lh) ^ (((kw + lr) >> 2) & 3)) << 4));
+            boff[kw][s_] = (unsigned)((RPW * wave * HWP + kw + lr) * 64 + (((2 * s_ + lh) ^ (((kw + lr) >> 2) & 3)) << 4));
     }
 
-    f32x16 acc[2][2];              // [row j][cout fragment]
+    f32x16 acc[RPW][2];            // [row j][cout fragment]
     auto zero_acc = [&]() {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < RPW; ++j)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1002,11 +1032,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_dma_kernel(ConvArgs a, int nTi
     // column tap changes) are requested before the 8 MFMAs of step n are issued (two fragment sets).
     auto compute = [&](int stage) {
         const char* sb = smem + stage * STAGE_BYTES;
-        uint4 fb[2][4][2];         // [set][halo row 2 wave + h][k-step]
+        uint4 fb[2][RPW + 2][2];   // [set][halo row RPW wave + h][k-step]
         uint4 fa[2][2][2];         // [set][cout fragment][k-step]
         auto load_b = [&](int set, int kw) {
 #pragma unroll
-            for (int h = 0; h < 4; ++h)
+            for (int h = 0; h < RPW + 2; ++h)
 #pragma unroll
                 for (int s_ = 0; s_ < 2; ++s_)
                     fb[set][h][s_] = *reinterpret_cast<const uint4*>(sb + h * (HWP * 64) + boff[kw][s_]);
@@ -1020,7 +1050,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_dma_kernel(ConvArgs a, int nTi
         };
         load_b(0, 0);
         load_a(0, 0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * (RPW + 2) + 4, 0);
 #pragma unroll
         for (int step = 0; step < 9; ++step) {
             const int kw = step / 3, kh = step % 3;
@@ -1030,70 +1060,91 @@ __global__ __launch_bounds__(512, 2) void conv3x3_dma_kernel(ConvArgs a, int nTi
                 load_a((step + 1) & 1, nkh, nkw);
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < RPW; ++j)
 #pragma unroll
                 for (int cf = 0; cf < 2; ++cf) Mma<E>::run(fa[step & 1][cf], fb[kw & 1][j + kh], acc[j][cf]);
             if (step < 8) {
-                if (nkh == 0) __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+                if (nkh == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2 * (RPW + 2) + 4, 0);
                 else __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x8, 4 * RPW, 0);
         }
     };
-    auto epilogue = [&](const DmaTile& tl) {
+    // Epilogue, written for a low instruction count: it runs once per tile on all eight waves at once, so nothing hides its
+    // VALU issue time (timing switches, profiles/r03_dma_switches.txt: 74 us of a 156 us two-chunk convolution in the first
+    // version -- 22 us stores, 12 us bias round trips, the rest instruction issue and instruction-cache misses of eight
+    // inlined copies x six activation variants = 14 700 instructions).  Now: one unrolled pass per activation CLASS (chosen
+    // by one wave-uniform branch outside), biases from LDS, one 64-bit address per tile and wave, pointer bumps after that.
+    auto epilogue_as = [&](const DmaTile& tl, int biasSlot, auto actTag) {
+        constexpr int ACT = decltype(actTag)::value;       // 0: max(v, slope v)   1: DCN offsets / masks   2: SiLU
+        const float slope = a.act == FLAIR_ACT_NONE ? 1.f : a.act == FLAIR_ACT_RELU ? 0.f : a.act == FLAIR_ACT_LRELU01 ? 0.1f : 0.2f;
+        const long p0 = ((long)tl.t * H + tl.h0 + RPW * wave) * W + tl.w0 + lr;          // this lane's pixel in row j = 0
+        const int cl = 8 * lh;                                                           // this lane's cout offset inside a 16-cout half
+        E* yb = reinterpret_cast<E*>(a.y) + p0 * a.yLd + tl.co0 + cl;
+        const E* r0b = a.res0 ? reinterpret_cast<const E*>(a.res0) + p0 * a.res0Ld + tl.co0 + cl : nullptr;
+        const E* r1b = a.res1 ? reinterpret_cast<const E*>(a.res1) + p0 * a.res1Ld + tl.co0 + cl : nullptr;
+        const float* fbb = a.fbias ? a.fbias + (long)tl.t * a.fbiasLd + tl.co0 + cl : nullptr;
+        const float* bl = reinterpret_cast<const float*>(smem + BIAS_OFF + (biasSlot & 1) * 256) + cl;
+        const float scale = a.outScale;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int h = tl.h0 + 2 * wave + j, w = tl.w0 + lr;
-            const long p = ((long)tl.t * H + h) * W + w;
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int jj = 0; jj < 2; ++jj) {
+                const int cofs = i * 32 + 16 * jj;                                       // cout offset of this group inside the tile
+                if (tl.co0 + cofs + cl >= a.Cout) continue;                              // (Cout % 8 == 0)
+                float bv[8];
+                {
+                    const float4 b0 = *reinterpret_cast<const float4*>(bl + cofs);
+                    const float4 b1 = *reinterpret_cast<const float4*>(bl + cofs + 4);
+                    bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+                    if (fbb) {
 #pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
-                    const int co = tl.co0 + i * 32 + 16 * jj + 8 * lh;
+                        for (int e = 0; e < 8; ++e) bv[e] += fbb[cofs + e];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < RPW; ++j) {
                     float v[8];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const auto sw2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[j][i][8 * jj + e]),
                                                                           __float_as_uint(acc[j][i][8 * jj + 4 + e]), false, false);
-                        v[e] = __uint_as_float(sw2[0]);
-                        v[4 + e] = __uint_as_float(sw2[1]);
+                        v[e] = __uint_as_float(sw2[0]) + bv[e];
+                        v[4 + e] = __uint_as_float(sw2[1]) + bv[4 + e];
                     }
-                    if (co >= a.Cout) continue;
-                    if (a.bias) {
-                        const float4 b0 = *reinterpret_cast<const float4*>(a.bias + co);
-                        const float4 b1 = *reinterpret_cast<const float4*>(a.bias + co + 4);
-                        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-                        v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-                    }
-                    if (a.fbias) {
-                        const float* fb_ = a.fbias + (long)tl.t * a.fbiasLd + co;
+                    if constexpr (ACT == 0) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += fb_[e];
-                    }
-                    if (a.act == FLAIR_ACT_DCN_OFFSETS) {
-                        dcn_offset_act<8>(v, co, a.actParam, a.actPeriod);
+                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], v[e] * slope);
+                    } else if constexpr (ACT == 1) {
+                        dcn_offset_act<8>(v, tl.co0 + cofs + cl, a.actParam, a.actPeriod);
                     } else {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], a.act);
+                        for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
                     }
-                    if (a.res0) {
+                    const long ro = (long)j * W;                                         // row j of the wave's pair
+                    if (r0b) {
                         float r[8];
-                        Vec16<E>::load(reinterpret_cast<const E*>(a.res0) + p * a.res0Ld + co, r);
+                        Vec16<E>::load(r0b + ro * a.res0Ld + cofs, r);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] += r[e];
                     }
-                    if (a.res1) {
+                    if (r1b) {
                         float r[8];
-                        Vec16<E>::load(reinterpret_cast<const E*>(a.res1) + p * a.res1Ld + co, r);
+                        Vec16<E>::load(r1b + ro * a.res1Ld + cofs, r);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] += r[e];
                     }
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] *= a.outScale;
-                    Vec16<E>::store(reinterpret_cast<E*>(a.y) + p * a.yLd + co, v);
+                    for (int e = 0; e < 8; ++e) v[e] *= scale;
+                    if (FLAIR_DBG(a) != 16) Vec16<E>::store(yb + ro * a.yLd + cofs, v);
+                    else asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
                 }
             }
-        }
+    };
+    auto epilogue = [&](const DmaTile& tl, int biasSlot) {
+        if (a.act == FLAIR_ACT_DCN_OFFSETS) epilogue_as(tl, biasSlot, std::integral_constant<int, 1>{});
+        else if (a.act == FLAIR_ACT_SILU) epilogue_as(tl, biasSlot, std::integral_constant<int, 2>{});
+        else epilogue_as(tl, biasSlot, std::integral_constant<int, 0>{});      // NONE / RELU / LeakyReLU (GELU: refused on the host)
     };
 
     // ---- the (tile, chunk) pipeline.  `cur` is the tile being multiplied, `nxt` the tile whose chunks are being issued.
@@ -1104,6 +1155,23 @@ __global__ __launch_bounds__(512, 2) void conv3x3_dma_kernel(ConvArgs a, int nTi
     Walk wk;
     walk_first(nxt.t, wk);
     setup_tile(nxt);
+    // biases of a tile: requested when its first chunk is issued (threads 0..15, one float4 each), written to the LDS slot
+    // of the tile's parity after the MFMA phase that follows, read in its epilogue at least one barrier later
+    float4 biasReg = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool biasPending = false;
+    auto bias_request = [&](const DmaTile& tl) {
+        if (tid < 16) {
+            const int bco = tl.co0 + 4 * tid;
+            biasReg = (a.bias && bco < a.Cout) ? *reinterpret_cast<const float4*>(a.bias + bco) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        biasPending = true;
+    };
+    auto bias_commit = [&](int slot_) {
+        if (tid < 16) *reinterpret_cast<float4*>(smem + BIAS_OFF + (slot_ & 1) * 256 + 16 * tid) = biasReg;
+        biasPending = false;
+    };
+    bias_request(nxt);
+    bias_commit(0);
     int remIssue = chunks_of(nxt.t);           // chunks of `nxt` not yet issued
     int remCompute = remIssue;                 // chunks of `cur` not yet multiplied
     bool more = true;                          // is there a chunk left to issue
@@ -1124,6 +1192,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_dma_kernel(ConvArgs a, int nTi
                 walk_first(nxt.t, wk);
                 setup_tile(nxt);
                 remIssue = chunks_of(nxt.t);
+                bias_request(nxt);
             }
         }
         if (more) {
@@ -1132,23 +1201,39 @@ __global__ __launch_bounds__(512, 2) void conv3x3_dma_kernel(ConvArgs a, int nTi
             --remIssue;
         }
         if (FLAIR_DBG(a) != 11) compute(stage);
+        if (biasPending) bias_commit(iNxt);
+        bool storesInFlight = false;
         if (--remCompute == 0) {
-            if (FLAIR_DBG(a) != 13) epilogue(cur);
+            if (FLAIR_DBG(a) != 13) {
+                epilogue(cur, iCur);
+                // a tile whose 64 couts all exist issues exactly 4 * RPW store instructions per wave, after this iteration's DMA
+                storesInFlight = cur.co0 + 64 <= a.Cout && FLAIR_DBG(a) != 14;
+            }
             ++iCur;
             if (!tile_at(iCur, cur)) break;
             remCompute = chunks_of(cur.t);
             zero_acc();
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces of the next stage have landed ...
+        // This wave's DMA pieces of the next stage have landed: vmcnt counts loads, LDS-DMA and stores in issue order, so
+        // with the 8 epilogue stores as the youngest operations vmcnt(8) retires every DMA and leaves the stores in flight
+        // (waiting for their acknowledgement from memory cost 40 % of a two-chunk convolution: profiles/r03_dma_switches.txt)
+        if (storesInFlight) {
+            if constexpr (RPW == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __syncthreads();                                      // ... and so have everybody else's
         stage ^= 1;
     }
 }
 
+template <int NW, int RPW>
 int launch_dma(const ConvArgs& a0, hipStream_t s) {
+    constexpr int TH = NW * RPW;
     ConvArgs a = a0;
     a.nCoTiles = cdiv(a.Cout, 64);
-    const int nTiles = a.T * (a.H / 16) * (a.W / 32) * a.nCoTiles;
+    const int nTiles = a.T * (a.H / TH) * (a.W / 32) * a.nCoTiles;
     static int nCu = 0;
     if (!nCu) {
         int dev = 0;
@@ -1159,15 +1244,16 @@ int launch_dma(const ConvArgs& a0, hipStream_t s) {
     int grid = nTiles < nCu ? (nTiles + 7) / 8 * 8 : nCu / 8 * 8;      // a multiple of 8: every XCD gets the same number of slots
     if (grid < 8) grid = 8;
     const int tilesPerXcd = (nTiles + 7) / 8;
-    const size_t lds = 2 * 76800 + 5 * 1024;       // two stages + the idle DMA slots' scratch
+    constexpr int HALO_INSTR = ((TH + 2) * 34 + 15) / 16;
+    const size_t lds = 2 * (size_t)(HALO_INSTR + 36) * 1024 + NW * 1024 + 512;  // two stages + idle DMA slots' scratch + two bias slots
     static bool attr = false;
     if (!attr) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_dma_kernel<0>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_dma_kernel<NW, RPW>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         FLAIR_CHECK(e == hipSuccess, "flair_conv_nhwc: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr = true;
     }
-    hipLaunchKernelGGL(conv3x3_dma_kernel<0>, dim3(grid), dim3(512), lds, s, a, nTiles, tilesPerXcd);
+    hipLaunchKernelGGL((conv3x3_dma_kernel<NW, RPW>), dim3(grid), dim3(64 * NW), lds, s, a, nTiles, tilesPerXcd);
     FLAIR_LAUNCH_CHECK();
     return FLAIR_OK;
 }
@@ -1437,9 +1523,17 @@ int choose_variant(const ConvArgs& a) {
         const bool ks = a.Cout % 8 == 0;
         // persistent LDS-DMA kernel (bf16): launches of more than one round of 8-row tiles whose 16-row tiles fill most CUs
         static const bool useDma = !(getenv("FLAIR_CONV_DMA") && atoi(getenv("FLAIR_CONV_DMA")) == 0);
-        if (useDma && a.esz == 2 && ks && a.H % 16 == 0 && per * cdiv(a.H, 8) > 256 && per * (a.H / 16) >= 192) return 8;
-        if (per * cdiv(a.H, 8) >= 256) return ks && per * cdiv(a.H, 8) <= 256 ? 6 : 3;
-        if (per * cdiv(a.H, 4) >= 256) return ks && per * cdiv(a.H, 4) <= 256 ? 7 : 4;
+        if (useDma && a.esz == 2 && ks && a.act != FLAIR_ACT_GELU && a.H % 16 == 0 && per * cdiv(a.H, 8) > 256 && per * (a.H / 16) >= 192) return 8;
+        // single-round launches (per-frame convolutions): the one-tile-per-workgroup forms of the LDS-DMA kernel (bf16)
+        // FLAIR_CONV_DMA_FRAME: 0 K-split kernels everywhere, 1 (default) <8 rows> form at the 256^2 level, 2 also the <4 rows>
+        // form at the 128^2 level.  Measured (profiles/r03_dma_switches.txt): a per-frame launch is launch (1.6 us) + cold first
+        // fetch (~4 us: every CU pulls its 58 KB at once after the boundary invalidated the L2s) + epilogue / drain (~3 us)
+        // whatever the staging mechanism: <8 rows> 12.6 vs 13.6 us on 64->64, equal on 224->64; <4 rows> 14.3 vs 11.9 us (one
+        // wave per SIMD does not hide the per-chunk DMA round trips that 8 K-split waves do), hence off by default.
+        static const int dmaFrame = getenv("FLAIR_CONV_DMA_FRAME") ? atoi(getenv("FLAIR_CONV_DMA_FRAME")) : 1;
+        const bool dmaOk = a.esz == 2 && ks && a.act != FLAIR_ACT_GELU;
+        if (per * cdiv(a.H, 8) >= 256) return ks && per * cdiv(a.H, 8) <= 256 ? (dmaOk && dmaFrame >= 1 && a.H % 8 == 0 ? 9 : 6) : 3;
+        if (per * cdiv(a.H, 4) >= 256) return ks && per * cdiv(a.H, 4) <= 256 ? (dmaOk && dmaFrame >= 2 && a.H % 4 == 0 ? 10 : 7) : 4;
         return 5;
     }
     const long tiles128 = (long)cdiv(a.P, 128) * cdiv(a.Cout, 128);
@@ -1473,7 +1567,9 @@ int dispatch(const ConvArgs& a0, hipStream_t s) {
             return rpw2 ? launch_halo_ks<E, 8, 2, 2>(a, s) : launch_halo_ks<E, 8, 1, 2>(a, s);
         }
         case 7: return launch_halo_ks<E, 4, 1, 2>(a, s);   // (two rows per wave leave 4 waves per CU here: +3.5 ms/step)
-        case 8: return launch_dma(a, s);
+        case 8: return launch_dma<8, 2>(a, s);
+        case 9: return launch_dma<8, 1>(a, s);
+        case 10: return launch_dma<4, 1>(a, s);
         default: return launch_halo<E, 2, 1, 1>(a, s);
     }
 }
@@ -1487,6 +1583,7 @@ static void fill_geometry(ConvArgs& a, const flair_conv_params* p) {
     a.Hin = p->H; a.Win = p->W;
     a.T = p->T; a.KT = p->KT; a.KH = p->KH; a.KW = p->KW; a.Cout = p->Cout;
     a.reflect = p->reflect_pad ? 1 : 0;
+    a.act = p->act;
     a.H = (p->H + a.stride - 1) / a.stride;       // "same"-style padding K/2: out = ceil(in / stride)
     a.W = (p->W + a.stride - 1) / a.stride;
     a.P = (long)p->T * a.H * a.W;

@@ -139,16 +139,18 @@ def test_conv_chain(dev, dtype, case):
 
 
 def test_conv_cases_cover_every_kernel_variant():
-    """The geometries above dispatch to all 9 conv kernel variants (flair_conv_variant)."""
+    """The geometries above dispatch to the 10 conv kernel variants in use (flair_conv_variant; variant 10, the 4-row
+    one-tile LDS-DMA form, is selected with FLAIR_CONV_DMA_FRAME=2 only)."""
     ops = _ops()
     geo = [(2, 16, 16, [64], 64, (1, 3, 3)), (16, 64, 64, [64], 64, (1, 3, 3)), (2, 128, 128, [64, 64], 64, (1, 3, 3)),
            (1, 64, 32, [128], 432, (1, 3, 3)), (1, 30, 32, [64, 64, 64, 32], 64, (1, 3, 3)),
            (16, 72, 64, [32], 64, (3, 3, 3)), (2, 136, 128, [64], 64, (1, 3, 3)),
            (1, 256, 256, [64, 32], 64, (1, 3, 3)), (4, 64, 64, [64], 128, (3, 3, 3)),
            (16, 256, 256, [64], 64, (1, 1, 1)), (16, 128, 128, [128], 128, (1, 1, 1)), (16, 4, 4, [512], 512, (3, 3, 3)),
-           (4, 128, 128, [64], 128, (1, 3, 3)), (16, 264, 256, [64], 64, (1, 3, 3))]
+           (4, 128, 128, [64], 128, (1, 3, 3)), (16, 264, 256, [64], 64, (1, 3, 3)),
+           (1, 250, 256, [64], 64, (1, 3, 3)), (1, 125, 128, [32], 128, (1, 3, 3))]
     seen = {ops.conv_variant(T, H, W, segs, cout, k) for T, H, W, segs, cout, k in geo}
-    assert seen == set(range(9)), seen
+    assert seen == set(range(10)), seen
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
