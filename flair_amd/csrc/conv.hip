@@ -1091,13 +1091,17 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
                 const int cofs = i * 32 + 16 * jj;                                       // cout offset of this group inside the tile
-                if (tl.co0 + cofs + cl >= a.Cout) continue;                              // (Cout % 8 == 0)
+                if (tl.co0 + cofs >= a.Cout) continue;                                   // wave-uniform: the whole 16-cout group is padding
+                // (Cout % 8 == 0) the upper 8 couts of the group may be padding: those lanes still take part in the
+                // v_permlane32_swap below (a swap under a divergent branch hands the active half garbage), only their
+                // loads / stores are predicated
+                const bool lane_ok = tl.co0 + cofs + cl < a.Cout;
                 float bv[8];
                 {
                     const float4 b0 = *reinterpret_cast<const float4*>(bl + cofs);
                     const float4 b1 = *reinterpret_cast<const float4*>(bl + cofs + 4);
                     bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
-                    if (fbb) {
+                    if (fbb && lane_ok) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) bv[e] += fbb[cofs + e];
                     }
@@ -1122,13 +1126,13 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
                         for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
                     }
                     const long ro = (long)j * W;                                         // row j of the wave's pair
-                    if (r0b) {
+                    if (r0b && lane_ok) {
                         float r[8];
                         Vec16<E>::load(r0b + ro * a.res0Ld + cofs, r);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] += r[e];
                     }
-                    if (r1b) {
+                    if (r1b && lane_ok) {
                         float r[8];
                         Vec16<E>::load(r1b + ro * a.res1Ld + cofs, r);
 #pragma unroll
@@ -1136,6 +1140,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
                     }
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] *= scale;
+                    if (!lane_ok) continue;
                     if (FLAIR_DBG(a) != 16) Vec16<E>::store(yb + ro * a.yLd + cofs, v);
                     else asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
                 }

@@ -499,7 +499,14 @@ extern "C" int flair_dcn_align(const flair_dcn_params* p, const void* x0, const 
     // couts with 8 threads per pixel, so one gather instruction fetches the whole 128-byte channel row of a
     // corner (two waves share each MFMA pair, K split); c=128: 32 pixels x 128 couts, 8 threads per pixel.
     if (p->dtype == FLAIR_BF16) {
-        if (p->Cout > 64) return launch_dcn<bf16_t, 4, 1, 8>(a, stream);
+        if (p->Cout > 64) {
+            // c = 128: every workgroup streams the whole 590 KB weight matrix, so the pixel tile sets the weight traffic
+            // (32-pixel tiles: 512 workgroups x 590 KB = 302 MB per 128x128 frame against 151 MB of gathers).
+            // FLAIR_DCN_TILE_C128 = 64: 64-pixel tiles (8 waves, one workgroup per CU on a 128x128 frame) halve it.
+            static const int tile128 = getenv("FLAIR_DCN_TILE_C128") ? atoi(getenv("FLAIR_DCN_TILE_C128")) : 32;
+            if (tile128 >= 64 && a.P >= 64 * 256) return launch_dcn<bf16_t, 4, 2, 8>(a, stream);
+            return launch_dcn<bf16_t, 4, 1, 8>(a, stream);
+        }
         // 64-pixel tiles need 47 KB of LDS: 3 workgroups per CU, so a 256x256 frame (1024 tiles) runs as 768 + 256
         // (a second, one-third-full round).  128-pixel tiles (78 KB, 2 per CU, 16 wavefronts each) make it one full round.
         static const int wide = getenv("FLAIR_DCN_TILE") ? atoi(getenv("FLAIR_DCN_TILE")) : 128;

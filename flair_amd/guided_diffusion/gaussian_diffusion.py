@@ -74,10 +74,8 @@ class GaussianDiffusion:
     """Sampling utilities (gaussian_diffusion.py:95-689)."""
 
     def __init__(self, *, betas, model_mean_type, model_var_type, loss_type, rescale_timesteps=False):
-        if model_mean_type != ModelMeanType.EPSILON:
-            raise NotImplementedError("flair_amd: FLAIR samples with ModelMeanType.EPSILON")
-        if model_var_type == ModelVarType.LEARNED:
-            raise NotImplementedError("flair_amd: ModelVarType.LEARNED is not used by FLAIR")
+        if model_mean_type not in (ModelMeanType.EPSILON, ModelMeanType.START_X, ModelMeanType.PREVIOUS_X):
+            raise NotImplementedError(model_mean_type)
         self.model_mean_type = model_mean_type
         self.model_var_type = model_var_type
         self.loss_type = loss_type
@@ -160,18 +158,33 @@ class GaussianDiffusion:
         assert t.shape == (B,)
         i = _uniform_step(t) if _step is None else _step
         model_output = model(x, self._scale_timesteps(t), **model_kwargs).float().contiguous()
-        learned = self.model_var_type == ModelVarType.LEARNED_RANGE
+        learned = self.model_var_type in (ModelVarType.LEARNED_RANGE, ModelVarType.LEARNED)
         if learned:
             assert model_output.shape == (B, C * 2, *x.shape[2:])
         x = x.float().contiguous()
         f32 = lambda v: float(np.float32(v))  # noqa: E731  (the reference casts table entries to f32)
-        pred_xstart = ops.predict_xstart(x, model_output, f32(self.sqrt_recip_alphas_cumprod[i]),
-                                         f32(self.sqrt_recipm1_alphas_cumprod[i]), clip_denoised)
+        # pred_xstart = clamp(a * x - b * model_output[:, :C]) for all three mean parametrisations (gaussian_diffusion.py:316-333):
+        #   EPSILON     a = sqrt(1/acp), b = sqrt(1/acp - 1);   START_X  a = 0, b = -1;
+        #   PREVIOUS_X  (xprev - coef2 x) / coef1:  a = -coef2 / coef1, b = -1 / coef1
+        if self.model_mean_type == ModelMeanType.EPSILON:
+            ca, cb = f32(self.sqrt_recip_alphas_cumprod[i]), f32(self.sqrt_recipm1_alphas_cumprod[i])
+        elif self.model_mean_type == ModelMeanType.START_X:
+            ca, cb = 0.0, -1.0
+        else:
+            ca = -f32(self.posterior_mean_coef2[i] / self.posterior_mean_coef1[i])
+            cb = -f32(1.0 / self.posterior_mean_coef1[i])
+        pred_xstart = ops.predict_xstart(x, model_output, ca, cb, clip_denoised)
         out = {"pred_xstart": pred_xstart}
         if _moments:
-            out["mean"] = ops.axpby(pred_xstart, x, f32(self.posterior_mean_coef1[i]),
-                                    f32(self.posterior_mean_coef2[i]))
-            if learned:
+            if self.model_mean_type == ModelMeanType.PREVIOUS_X:
+                out["mean"] = model_output[:, :C].contiguous()
+            else:
+                out["mean"] = ops.axpby(pred_xstart, x, f32(self.posterior_mean_coef1[i]),
+                                        f32(self.posterior_mean_coef2[i]))
+            if self.model_var_type == ModelVarType.LEARNED:
+                # log-variance = the raw second half of the output: frac * max + (1 - frac) * min with min = -1, max = 1
+                var, logvar = ops.learned_range_variance(model_output, C, -1.0, 1.0)
+            elif learned:
                 var, logvar = ops.learned_range_variance(
                     model_output, C, f32(self.posterior_log_variance_clipped[i]), f32(np.log(self.betas[i])))
             else:

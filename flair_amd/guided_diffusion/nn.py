@@ -31,8 +31,22 @@ def normalization(channels, *args, **kwargs):
 
 
 def flash_attn_wrapper(q, k, v, dropout):
-    """nn.py:370-386 is the flash-attn entry of TemporalAttention; its replacement is the fused
-    window-attention kernel (``flair_amd.ops.temporal_attention``), which consumes the packed
-    q|k|v clip tensor directly.  There is no (B, L, heads, D) entry point."""
-    raise NotImplementedError("flair_amd: use ops.temporal_attention (fused window attention); "
-                              "flash_attn_wrapper's (B,L,H,D) calling convention is not provided")
+    """nn.py:370-386: ``flash_attn_func`` on (B, L, heads, D) tensors after a cast to fp16, result cast back --
+    exact softmax(q k^T / sqrt(D)) v per head.  TemporalAttention itself runs on the fused window-attention kernel
+    (``flair_amd.ops.temporal_attention``, which consumes the packed q|k|v clip tensor); this entry keeps the reference's
+    calling convention for other callers: q | k | v are packed into one (B, 1, L, 3*heads*D) clip tensor and handed to
+    ``flair_attention_wide`` (inputs rounded through fp16 like the reference's cast; dropout must be 0: inference)."""
+    import torch
+    from .. import ops
+    if dropout:
+        raise NotImplementedError("flair_amd: flash_attn_wrapper is an inference entry (dropout must be 0)")
+    if not q.is_cuda:
+        raise RuntimeError("flair_amd.nn.flash_attn_wrapper runs on the MI355X only (tensors must be on 'cuda')")
+    B, L, Hh, D = q.shape
+    dt = q.dtype
+    work = torch.bfloat16 if dt == torch.bfloat16 else torch.float32
+    parts = [t.contiguous().to(torch.float16).to(work).reshape(B, 1, L, Hh * D) for t in (q, k, v)]
+    qkv = torch.cat(parts, dim=-1).contiguous()
+    C = Hh * D
+    out = ops.attention_wide(qkv, Hh, D, q_off=0, k_off=C, v_off=2 * C, head_stride=D)
+    return out.reshape(B, L, Hh, D).to(dt)

@@ -417,6 +417,14 @@ int flair_face_mask_blur(const int* parse_idx, int N, int H, int W, const double
 int flair_face_blend(const float* x0, const float* face, const float* mask, int N, int C, int H, int W, float* out,
                      hipStream_t stream);
 
+/* ------------------------------------------------------------- multi-GPU start-up
+ * The only collective of the path: in-place RCCL broadcast of the kernel-native weight blob (flair_amd.checkpoint.export_packed:
+ * bf16 [Cout][taps][Cin] conv weights, batched embedding matrix, f32 biases ...) from `root` to every rank of `rccl_comm`
+ * (an ncclComm_t of the host process), enqueued on `stream`.  Replaces dist_util.py:40-79 (pickled-chunk load_state_dict +
+ * one broadcast per parameter).  librccl is bound with dlopen at the first call.  Clips are independent after that: no
+ * data-path collective exists. */
+int flair_bcast_weights(void* blob, size_t bytes, int root, void* rccl_comm, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

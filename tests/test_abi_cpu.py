@@ -50,3 +50,13 @@ def test_argument_errors_are_reported_without_a_gpu():
     rc = lib.flair_conv_nhwc(ctypes.byref(p), (ctypes.c_void_p * 4)(1, 0, 0, 0), ctypes.c_void_p(16), None, None,
                              None, None, ctypes.c_void_p(16), None, ctypes.c_size_t(0), None)
     assert rc == -1 and b"bad dtype" in lib.flair_last_error()
+
+
+def test_bcast_entry_validates_arguments():
+    """flair_bcast_weights (the path's only collective) refuses a null blob / communicator with a message and
+    does not touch RCCL for that (no GPU and no librccl needed here)."""
+    import ctypes
+    from flair_amd import _lib
+    lib = _lib.lib()
+    rc = lib.flair_bcast_weights(None, ctypes.c_size_t(0), 0, None, None)
+    assert rc == -1 and b"flair_bcast_weights" in lib.flair_last_error()

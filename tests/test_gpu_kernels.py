@@ -51,6 +51,9 @@ def _ops():
     (8, 128, 128, [64], 128, (1, 3, 3), 3, 2),
     (3, 256, 256, [32], 64, (1, 3, 3), 2, 0),
     (6, 64, 128, [32, 32], 128, (3, 3, 3), 1, 1),
+    (6, 64, 128, [64], 128, (3, 3, 3), 0, 0),
+    (3, 256, 256, [32], 8, (1, 3, 3), 0, 1),        # 8 couts: half of every 16-cout store group is padding
+    (6, 128, 128, [96], 64, (3, 3, 3), 0, 1),
     (1, 128, 128, [128], 432, (1, 3, 3), 0, 0),
     (2, 128, 256, [64, 32, 64, 32], 64, (1, 3, 3), 2, 2),
     # deep-K convolutions on few pixels: 128 x 128 tiles with split-K (16x16 / 8x8 levels)
@@ -411,3 +414,25 @@ def test_error_paths(dev):
         ops.conv(x, w, None, 8, (1, 3, 3))
     with pytest.raises(_lib.FlairHipError):
         ops.conv(torch.zeros(1, 4, 4, 32), torch.zeros(8, 9, 32), None, 8, (1, 3, 3))  # CPU tensors
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_flash_attn_wrapper_calling_convention(dev, dtype):
+    """nn.flash_attn_wrapper(q, k, v, dropout) on (B, L, heads, D) tensors (nn.py:370-386) against exact attention on the
+    fp16-rounded inputs (flash-attn itself is absent: published definition softmax(q k^T / sqrt(D)) v, parity unpinned)."""
+    from flair_amd.guided_diffusion import nn as fnn
+    g = torch.Generator().manual_seed(12)
+    B, L, Hh, D = 6, 5, 2, 64
+    q, k, v = (torch.randn(B, L, Hh, D, generator=g) for _ in range(3))
+    qh, kh, vh = (t.half().float() for t in (q, k, v))
+    if dtype == torch.bfloat16:
+        qh, kh, vh = (t.bfloat16().float() for t in (qh, kh, vh))
+    att = torch.softmax(torch.einsum("blhd,bmhd->bhlm", qh, kh) / math.sqrt(D), dim=-1)
+    ref = torch.einsum("bhlm,bmhd->blhd", att, vh)
+    got = fnn.flash_attn_wrapper(q.to(dev).to(dtype), k.to(dev).to(dtype), v.to(dev).to(dtype), 0.0)
+    torch.cuda.synchronize()
+    assert got.shape == (B, L, Hh, D) and got.dtype == dtype
+    assert_close(got.float().cpu(), ref, dtype, "flash_attn_wrapper")
+    with pytest.raises(NotImplementedError):
+        fnn.flash_attn_wrapper(q.to(dev), k.to(dev), v.to(dev), 0.1)

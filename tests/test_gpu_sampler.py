@@ -220,6 +220,49 @@ def test_p_mean_variance_moments(dev, learned):
     assert abs(float(qlv.flatten()[0]) - np.log(1.0 - tab.alphas_cumprod[i])) <= 1e-5
 
 
+@pytest.mark.parametrize("mean_type,var_type", [("START_X", "FIXED_SMALL"), ("PREVIOUS_X", "LEARNED"), ("EPSILON", "LEARNED")])
+def test_other_mean_and_variance_parametrisations(dev, mean_type, var_type):
+    """ModelMeanType.START_X / PREVIOUS_X and ModelVarType.LEARNED (gaussian_diffusion.py:278-333; not used by the shipped
+    configurations, which are EPSILON + LEARNED_RANGE / FIXED_SMALL) against the reference's formulas evaluated in torch."""
+    from flair_amd.guided_diffusion import gaussian_diffusion as gd
+    from oracle import diffusion as odiff
+    betas = odiff.named_betas("face_blur", 1000)
+    d = gd.GaussianDiffusion(betas=betas, model_mean_type=getattr(gd.ModelMeanType, mean_type),
+                             model_var_type=getattr(gd.ModelVarType, var_type), loss_type=gd.LossType.MSE)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 3, 8, 8, generator=g)
+    learned = var_type == "LEARNED"
+    mo = torch.randn(2, 6 if learned else 3, 8, 8, generator=g) * 0.7
+    i = 417
+    t = torch.full((2,), i, dtype=torch.long)
+
+    class M:
+        def __call__(self, xx, tt, **kw):
+            return mo.to(dev)
+    got = d.p_mean_variance(M(), x.to(dev), t.to(dev), clip_denoised=True, model_kwargs={})
+    f = lambda a: float(np.float32(a[i]))      # noqa: E731
+    out = mo[:, :3]
+    if mean_type == "START_X":
+        x0 = out.clamp(-1, 1)
+        mean = f(d.posterior_mean_coef1) * x0 + f(d.posterior_mean_coef2) * x
+    elif mean_type == "PREVIOUS_X":
+        x0 = (float(np.float32(1.0 / d.posterior_mean_coef1[i])) * out
+              - float(np.float32(d.posterior_mean_coef2[i] / d.posterior_mean_coef1[i])) * x).clamp(-1, 1)
+        mean = out
+    else:
+        x0 = (f(d.sqrt_recip_alphas_cumprod) * x - f(d.sqrt_recipm1_alphas_cumprod) * out).clamp(-1, 1)
+        mean = f(d.posterior_mean_coef1) * x0 + f(d.posterior_mean_coef2) * x
+    if learned:
+        logvar = mo[:, 3:]
+        var = torch.exp(logvar)
+    else:
+        var = torch.full_like(x, f(d.posterior_variance))
+        logvar = torch.full_like(x, f(d.posterior_log_variance_clipped))
+    for name, ref in (("pred_xstart", x0), ("mean", mean), ("variance", var), ("log_variance", logvar)):
+        err = (got[name].cpu() - ref).abs().max().item()
+        assert err <= 2e-5 * max(1.0, ref.abs().max().item()), (name, err)
+
+
 _CHAIN = {}
 
 
