@@ -96,6 +96,7 @@ constexpr int CHAIN_MAX_COUTB = 512;   // stage-B biases are staged in LDS once
 
 template <typename E, int C, int TH, int TW, bool HASA>
 __global__ __launch_bounds__(512, 2) void conv_chain_kernel(ChainArgs a) {
+    prefetch_kernargs<sizeof(ChainArgs)>();
     constexpr int NT = 512, NW = 8;
     constexpr int BKE = MmaC<E>::BKE;
     constexpr int VEC = ET<E>::VEC;

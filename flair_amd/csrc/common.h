@@ -133,4 +133,33 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + (bid >> 3);
 }
 
+// Kernel-argument prefetch.  hipcc loads the by-value argument struct of a kernel (ConvArgs: 304 bytes = five 64-byte lines
+// of the kernarg segment) lazily, one s_load + s_waitcnt at a time as the prologue needs the fields: three to five DEPENDENT
+// scalar-cache misses, each a round trip to memory, before the first vector load can be issued.  A replayed forward is
+// ~2 600 such launches per step.  This touches every line of the argument block in ONE batch (one round trip); the
+// compiler's own loads then hit the scalar cache.  NBYTES = size of the explicit arguments (+ the implicit block behind them).
+template <int NBYTES>
+__device__ __forceinline__ void prefetch_kernargs() {
+#ifdef FLAIR_NO_KARG_PREFETCH
+    return;
+#endif
+    const auto ka = __builtin_amdgcn_kernarg_segment_ptr();
+    constexpr int LINES = (NBYTES + 63) / 64 + 1;
+    unsigned t0, t1, t2, t3, t4, t5, t6, t7;
+    if constexpr (LINES <= 2)
+        asm volatile("s_load_dword %0, %2, 0x0\n\ts_load_dword %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=&s"(t0), "=&s"(t1) : "s"(ka) : "memory");
+    else if constexpr (LINES <= 4)
+        asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80\n\ts_load_dword %3, %4, 0xc0\n\t"
+                     "s_waitcnt lgkmcnt(0)" : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3) : "s"(ka) : "memory");
+    else if constexpr (LINES <= 6)
+        asm volatile("s_load_dword %0, %6, 0x0\n\ts_load_dword %1, %6, 0x40\n\ts_load_dword %2, %6, 0x80\n\ts_load_dword %3, %6, 0xc0\n\t"
+                     "s_load_dword %4, %6, 0x100\n\ts_load_dword %5, %6, 0x140\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5) : "s"(ka) : "memory");
+    else
+        asm volatile("s_load_dword %0, %8, 0x0\n\ts_load_dword %1, %8, 0x40\n\ts_load_dword %2, %8, 0x80\n\ts_load_dword %3, %8, 0xc0\n\t"
+                     "s_load_dword %4, %8, 0x100\n\ts_load_dword %5, %8, 0x140\n\ts_load_dword %6, %8, 0x180\n\ts_load_dword %7, %8, 0x1c0\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6), "=&s"(t7) : "s"(ka) : "memory");
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -174,6 +174,79 @@ __device__ __forceinline__ void store_quad(const ConvArgs& a, long p, int co, fl
     }
 }
 
+// Epilogue of one 32 (couts) x 32 (pixels) accumulator fragment, low instruction count form (Cout % 8 == 0): after
+// v_permlane32_swap a lane holds 8 consecutive couts of its pixel per 16-cout half, so bias / residuals / output move as
+// 16-byte (bf16) or 2 x 16-byte (f32) pieces, and the activation is compiled for ONE class (ACT: 0 max(v, slope v) =
+// none / ReLU / LeakyReLU, 1 DCN offsets and masks, 2 SiLU, 3 exact GELU), chosen by one wave-uniform branch at the call
+// site.  store_quad above (8-byte pieces, six activation variants inlined per quad) made conv_igemm_kernel<128,128> 77 KB of
+// code, more than the instruction cache that two CUs share.  All lanes must call this (the swaps cross the half-waves).
+template <typename E, int ACT>
+__device__ __forceinline__ void store_frag32(const ConvArgs& a, const f32x16& c, long p, int co32, bool pvalid, int lh) {
+    const float slope = a.act == FLAIR_ACT_NONE ? 1.f : a.act == FLAIR_ACT_RELU ? 0.f : a.act == FLAIR_ACT_LRELU01 ? 0.1f : 0.2f;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        if (co32 + 16 * jj >= a.Cout) continue;                  // wave-uniform
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const auto sw2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(c[8 * jj + e]), __float_as_uint(c[8 * jj + 4 + e]), false, false);
+            v[e] = __uint_as_float(sw2[0]);
+            v[4 + e] = __uint_as_float(sw2[1]);
+        }
+        const int co = co32 + 16 * jj + 8 * lh;
+        if (!pvalid || co >= a.Cout) continue;
+        if (a.bias) {
+            const float4 b0 = *reinterpret_cast<const float4*>(a.bias + co);
+            const float4 b1 = *reinterpret_cast<const float4*>(a.bias + co + 4);
+            v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+            v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+        }
+        if (a.fbias) {
+            const float* fb = a.fbias + (p / ((long)a.H * a.W)) * a.fbiasLd + co;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += fb[e];
+        }
+        if constexpr (ACT == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], v[e] * slope);
+        } else if constexpr (ACT == 1) {
+            dcn_offset_act<8>(v, co, a.actParam, a.actPeriod);
+        } else if constexpr (ACT == 2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752f));
+        }
+        constexpr int VEC = ET<E>::VEC;                          // 8 (bf16: one 16-byte piece) or 4 (f32: two)
+        if (a.res0) {
+            const E* r = reinterpret_cast<const E*>(a.res0) + p * a.res0Ld + co;
+#pragma unroll
+            for (int q = 0; q < 8; q += VEC) {
+                float t[VEC];
+                Vec16<E>::load(r + q, t);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[q + e] += t[e];
+            }
+        }
+        if (a.res1) {
+            const E* r = reinterpret_cast<const E*>(a.res1) + p * a.res1Ld + co;
+#pragma unroll
+            for (int q = 0; q < 8; q += VEC) {
+                float t[VEC];
+                Vec16<E>::load(r + q, t);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[q + e] += t[e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= a.outScale;
+        E* dst = reinterpret_cast<E*>(a.y) + p * a.yLd + co;
+#pragma unroll
+        for (int q = 0; q < 8; q += VEC) Vec16<E>::store(dst + q, v + q);
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // 3x3 (x KT) convolution with an LDS-staged HALO tile.
 //
@@ -189,6 +262,7 @@ __device__ __forceinline__ void store_quad(const ConvArgs& a, long p, int co, fl
 template <typename E, int TH, int RPW, int PF>
 __global__ __launch_bounds__(64 * TH / RPW, (2 * 64 * TH / RPW + 255) / 256)  // two workgroups per CU
 void conv3x3_halo_kernel(ConvArgs a) {
+    prefetch_kernargs<sizeof(ConvArgs)>();
     constexpr int BKE = Mma<E>::BKE;
     constexpr int VEC = ET<E>::VEC;
     constexpr int NT = 64 * TH / RPW;              // one wavefront per RPW image rows
@@ -560,6 +634,7 @@ int launch_halo(const ConvArgs& a0, hipStream_t s) {
 // 256 VGPRs).  Needs Cout % 8 == 0.
 template <typename E, int TH, int RPW, int CF>
 __global__ __launch_bounds__(256 * TH / RPW / CF, (256 * TH / RPW / CF) / 256) void conv3x3_halo_ks_kernel(ConvArgs a) {
+    prefetch_kernargs<sizeof(ConvArgs)>();
     constexpr int NRG = TH / RPW;                  // row groups
     constexpr int NCG = 2 / CF;                    // cout-fragment groups (CF fragments of 32 couts per wave)
     constexpr int NW = 2 * NRG * NCG, NT = 64 * NW;
@@ -774,6 +849,8 @@ __global__ __launch_bounds__(256 * TH / RPW / CF, (256 * TH / RPW / CF) / 256) v
         __syncthreads();
     }
     if (!eok) return;
+    const float slope = a.act == FLAIR_ACT_NONE ? 1.f : a.act == FLAIR_ACT_RELU ? 0.f : a.act == FLAIR_ACT_LRELU01 ? 0.1f : 0.2f;
+    const bool leaky = a.act == FLAIR_ACT_NONE || a.act == FLAIR_ACT_RELU || a.act == FLAIR_ACT_LRELU01 || a.act == FLAIR_ACT_LRELU02;
     const char* tile = smem + orow * 32 * FPITCH;
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
@@ -793,8 +870,14 @@ __global__ __launch_bounds__(256 * TH / RPW / CF, (256 * TH / RPW / CF) / 256) v
 #pragma unroll
             for (int e = 0; e < VEC; ++e) v[e] += fb[e];
         }
-        if (a.act == FLAIR_ACT_DCN_OFFSETS) {
+        if (leaky) {                       // none / ReLU / LeakyReLU: max(v, slope v); one class per branch keeps the code short
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[e] = fmaxf(v[e], v[e] * slope);
+        } else if (a.act == FLAIR_ACT_DCN_OFFSETS) {
             dcn_offset_act<VEC>(v, eco, a.actParam, a.actPeriod);
+        } else if (a.act == FLAIR_ACT_SILU) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[e] = silu_f(v[e]);
         } else {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) v[e] = apply_act(v[e], a.act);
@@ -891,6 +974,7 @@ __device__ __forceinline__ u32x4_t make_desc(const void* base, unsigned bytes) {
 //   of load -> ds_write -> barrier) and the register epilogue (no LDS transposition, no k-half reduction barriers).
 template <int NW, int RPW>
 __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(ConvArgs a, int nTiles, int tilesPerXcd) {
+    prefetch_kernargs<sizeof(ConvArgs) + 8>();
     using E = bf16_t;
     constexpr int TH = NW * RPW, HWP = 34;                 // tile rows, halo pitch in pixels
     constexpr int HALO_ROWS = (TH + 2) * HWP;              // staged pixels
@@ -1030,7 +1114,8 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
     };
     // One chunk = 3 column taps x 3 row taps x 8 MFMAs.  Fragments of step n + 1 (A: 4 reads; B: 8 more reads when the
     // column tap changes) are requested before the 8 MFMAs of step n are issued (two fragment sets).
-    auto compute = [&](int stage) {
+    auto compute_as = [&](int stage, auto revTag) {
+        constexpr bool REV = decltype(revTag)::value;      // walk the column taps right to left (experiment: de-phase wave pairs)
         const char* sb = smem + stage * STAGE_BYTES;
         uint4 fb[2][RPW + 2][2];   // [set][halo row RPW wave + h][k-step]
         uint4 fa[2][2][2];         // [set][cout fragment][k-step]
@@ -1048,27 +1133,39 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
                 for (int s_ = 0; s_ < 2; ++s_)
                     fa[set][cf][s_] = *reinterpret_cast<const uint4*>(sb + (kh * 3 + kw) * 4096 + cf * 2048 + aoff[s_]);
         };
-        load_b(0, 0);
-        load_a(0, 0, 0);
+        auto KW = [](int q) { return REV ? 2 - q : q; };
+        load_b(0, KW(0));
+        load_a(0, 0, KW(0));
         __builtin_amdgcn_sched_group_barrier(0x100, 2 * (RPW + 2) + 4, 0);
 #pragma unroll
         for (int step = 0; step < 9; ++step) {
-            const int kw = step / 3, kh = step % 3;
-            const int nkw = (step + 1) / 3, nkh = (step + 1) % 3;
+            const int kq = step / 3, kh = step % 3;
+            const int nkq = (step + 1) / 3, nkh = (step + 1) % 3;
             if (step < 8) {
-                if (nkh == 0) load_b(nkw & 1, nkw);
-                load_a((step + 1) & 1, nkh, nkw);
+                if (nkh == 0) load_b(nkq & 1, KW(nkq));
+                load_a((step + 1) & 1, nkh, KW(nkq));
             }
+            if (FLAIR_DBG(a) == 17) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int j = 0; j < RPW; ++j)
 #pragma unroll
-                for (int cf = 0; cf < 2; ++cf) Mma<E>::run(fa[step & 1][cf], fb[kw & 1][j + kh], acc[j][cf]);
+                for (int cf = 0; cf < 2; ++cf) Mma<E>::run(fa[step & 1][cf], fb[kq & 1][j + kh], acc[j][cf]);
+            if (FLAIR_DBG(a) == 17) __builtin_amdgcn_s_setprio(0);
             if (step < 8) {
                 if (nkh == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2 * (RPW + 2) + 4, 0);
                 else __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
             }
             __builtin_amdgcn_sched_group_barrier(0x8, 4 * RPW, 0);
         }
+    };
+    auto compute = [&](int stage) {
+#ifdef FLAIR_TIMING_SWITCHES
+        if (FLAIR_DBG(a) == 18 && wave >= NW / 2) {
+            compute_as(stage, std::true_type{});
+            return;
+        }
+#endif
+        compute_as(stage, std::false_type{});
     };
     // Epilogue, written for a low instruction count: it runs once per tile on all eight waves at once, so nothing hides its
     // VALU issue time (timing switches, profiles/r03_dma_switches.txt: 74 us of a 156 us two-chunk convolution in the first
@@ -1266,6 +1363,7 @@ int launch_dma(const ConvArgs& a0, hipStream_t s) {
 // TC x TP block tile (couts x pixels), 4 waves arranged WC x WP.
 template <typename E, int TC, int TP, int WC, int WP>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+    prefetch_kernargs<sizeof(ConvArgs)>();
     constexpr int BKE = Mma<E>::BKE;
     constexpr int VEC = ET<E>::VEC;
     constexpr int FC = TC / WC / 32;  // 32x32 fragments per wave along cout
@@ -1454,8 +1552,26 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         }
         return;
     }
+    if ((a.Cout & 7) == 0 && ((uintptr_t)a.y & 15) == 0 && (a.yLd * (int)sizeof(E)) % 16 == 0 &&
+        (!a.res0 || (((uintptr_t)a.res0 & 15) == 0 && (a.res0Ld * (int)sizeof(E)) % 16 == 0)) &&
+        (!a.res1 || (((uintptr_t)a.res1 & 15) == 0 && (a.res1Ld * (int)sizeof(E)) % 16 == 0))) {
+        auto run = [&](auto actTag) {
+            constexpr int ACT = decltype(actTag)::value;
 #pragma unroll
-    for (int j = 0; j < FP; ++j) {
+            for (int j = 0; j < FP; ++j) {
+                const long p = p0 + wp * (TP / WP) + j * 32 + lr;
+#pragma unroll
+                for (int i = 0; i < FC; ++i) store_frag32<E, ACT>(a, acc[i][j], p, co0 + wc * (TC / WC) + i * 32, p < a.P, lh);
+            }
+        };
+        if (a.act == FLAIR_ACT_DCN_OFFSETS) run(std::integral_constant<int, 1>{});
+        else if (a.act == FLAIR_ACT_SILU) run(std::integral_constant<int, 2>{});
+        else if (a.act == FLAIR_ACT_GELU) run(std::integral_constant<int, 3>{});
+        else run(std::integral_constant<int, 0>{});
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < FP; ++j) {       // (a run-time j would index the accumulator array dynamically: scratch memory)
         const long p = p0 + wp * (TP / WP) + j * 32 + lr;
         if (p >= a.P) continue;
 #pragma unroll

@@ -116,6 +116,7 @@ __device__ __forceinline__ float fast_tanh(float x) {
 // for the c = 128 tiles, where only 8 wavefronts per CU exist to hide the gather round trip).
 template <typename E, int NCF, int NPF, int TPP, bool ACTIVATED, bool ONEFRAME, int PFD>
 __global__ __launch_bounds__(32 * NPF * TPP, (NCF >= 4 ? 32 * NPF * TPP / 256 : 4)) void dcn_kernel(DcnArgs a) {
+    prefetch_kernargs<sizeof(DcnArgs)>();
     constexpr int NT = 32 * NPF * TPP, NW = NT / 64;
     constexpr int TP = 32 * NPF, TC = 32 * NCF, CPR = TPP;
     constexpr int VEC = ET<E>::VEC;

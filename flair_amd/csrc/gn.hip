@@ -33,6 +33,7 @@ struct GnSrc {
 
 template <typename E>
 __global__ void gn_partial_kernel(GnSrc s, int C, int groups, long pixPerStat, int blocksPerStat, float* part) {
+    prefetch_kernargs<sizeof(GnSrc) + 32>();
     constexpr int VEC = ET<E>::VEC;
     extern __shared__ float red[];  // [2][rows][C]; row 0 of each plane ends up holding the channel totals
     const int cv = C / VEC;
@@ -155,6 +156,7 @@ struct GnApply {
 
 template <typename E>
 __global__ void gn_apply_kernel(GnApply a) {
+    prefetch_kernargs<sizeof(GnApply)>();
     constexpr int VEC = ET<E>::VEC;
     const int cv = a.C / VEC;
     const int rows = blockDim.x / cv;
@@ -285,6 +287,7 @@ __global__ void gn_apply_kernel(GnApply a) {
 // (every 16-byte piece sits in its own 128-byte line, 32 workgroups only) and was dropped.
 template <typename E>
 __global__ __launch_bounds__(1024) void gn_group_kernel(GnApply a, float eps) {
+    prefetch_kernargs<sizeof(GnApply) + 8>();
     constexpr int VEC = ET<E>::VEC;
     constexpr int NT = 1024, U = 4;
     extern __shared__ __attribute__((aligned(16))) char gsm[];

@@ -175,6 +175,7 @@ template <typename E>
 __global__ void vsrpp_warp2_kernel(const E* prop, int propLd, const E* feat2, int feat2Ld, const float* flow1,
                                    const float* flow2, int H, int W, int C, E* cond1, int cond1Ld, E* cond2,
                                    int cond2Ld) {
+    prefetch_kernargs<96>();
     constexpr int VEC = ET<E>::VEC;
     const int cv = C / VEC;
     const long total = (long)H * W * cv;

@@ -63,9 +63,18 @@ class SpacedDiffusion(GaussianDiffusion):
     def _wrap_model(self, model):
         if isinstance(model, _WrappedModel):
             return model
-        return _WrappedModel(model, self.timestep_map, self.rescale_timesteps, self.original_num_steps,
-                             noise_schedule=self.noise_schedule,
-                             sqrt_alphas_cumprod_prev=self.sqrt_alphas_cumprod_prev)
+        # one wrapper per (diffusion, model): its timestep table is uploaded once, not once per denoising step (the
+        # upload is a host-device synchronisation in the middle of every step: tools/probes/sync_probe.py)
+        cache = self.__dict__.setdefault("_wrapped", {})
+        w = cache.get(id(model))
+        if w is None or w.model is not model:
+            if len(cache) >= 8:
+                cache.clear()
+            w = _WrappedModel(model, self.timestep_map, self.rescale_timesteps, self.original_num_steps,
+                              noise_schedule=self.noise_schedule,
+                              sqrt_alphas_cumprod_prev=self.sqrt_alphas_cumprod_prev)
+            cache[id(model)] = w
+        return w
 
     def _scale_timesteps(self, t):
         return t  # done by the wrapped model
