@@ -972,7 +972,10 @@ __device__ __forceinline__ u32x4_t make_desc(const void* base, unsigned bytes) {
 //   <8, 1> / <4, 1> single-round launches of 256 tiles of 8 / 4 rows = the per-frame convolutions of the BasicVSR++
 //   recurrence at 256^2 (c = 64) and 128^2 (c = 128): one tile per workgroup, where the gain is the short prologue (DMA instead
 //   of load -> ds_write -> barrier) and the register epilogue (no LDS transposition, no k-half reduction barriers).
-template <int NW, int RPW>
+//   NSTAGE = 3 (one-tile launches only): three LDS stages, chunks n + 1 and n + 2 in flight while chunk n is multiplied (counted
+//   vmcnt): a per-frame launch at 128^2 multiplies a chunk in ~0.5 us but needs ~1.5 us to fetch one, so depth hides what
+//   a single chunk in flight cannot.
+template <int NW, int RPW, int NSTAGE>
 __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(ConvArgs a, int nTiles, int tilesPerXcd) {
     prefetch_kernargs<sizeof(ConvArgs) + 8>();
     using E = bf16_t;
@@ -983,7 +986,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
     constexpr int HALO_BYTES = HALO_INSTR * 1024;
     constexpr int STAGE_BYTES = HALO_BYTES + W_INSTR * 1024;
     constexpr int NSLOT = (HALO_INSTR + W_INSTR + NW - 1) / NW;   // DMA instructions per wave and chunk
-    constexpr int BIAS_OFF = 2 * STAGE_BYTES + NW * 1024;  // two slots of 64 f32 biases (tile parity) behind the DMA scratch
+    constexpr int BIAS_OFF = NSTAGE * STAGE_BYTES + NW * 1024;  // two slots of 64 f32 biases (tile parity) behind the DMA scratch
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1088,7 +1091,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
             // instruction ids past the last weight row (wave 7's tail slots) write their zeros to a scratch area behind the
             // two stages instead of the first bytes of the next stage
             const bool idle = wave * NSLOT + i >= HALO_INSTR + W_INSTR;
-            dma16(d, isw ? offw : offh, idle ? (unsigned)(2 * STAGE_BYTES + ((wave * NSLOT + i - HALO_INSTR - W_INSTR) % NW) * 1024) : sbase + i * 1024);
+            dma16(d, isw ? offw : offh, idle ? (unsigned)(NSTAGE * STAGE_BYTES + ((wave * NSLOT + i - HALO_INSTR - W_INSTR) % NW) * 1024) : sbase + i * 1024);
         }
     };
 
@@ -1274,6 +1277,30 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
     };
     bias_request(nxt);
     bias_commit(0);
+    if constexpr (NSTAGE == 3) {
+        // ---- one tile, three stages: wait(n) -> barrier -> issue(n + 2) -> multiply(n).  When chunk n is waited for, the only
+        // younger DMA in flight is chunk n + 1 (NSLOT instructions of this wave): vmcnt(NSLOT) retires chunk n and leaves it.
+        const int nch = chunks_of(cur.t);
+        issue(cur, wk, 0);
+        walk_next(cur.t, wk);
+        if (nch > 1) {
+            issue(cur, wk, 1);
+            walk_next(cur.t, wk);
+        }
+        zero_acc();
+        for (int n = 0; n < nch; ++n) {
+            if (n + 1 < nch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSLOT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                    // chunk n is in LDS for everybody; stage (n + 2) % 3 = (n - 1) % 3 is free
+            if (n + 2 < nch) {
+                if (FLAIR_DBG(a) != 12) issue(cur, wk, (n + 2) % 3);
+                walk_next(cur.t, wk);
+            }
+            if (FLAIR_DBG(a) != 11) compute(n % 3);
+        }
+        if (FLAIR_DBG(a) != 13) epilogue(cur, 0);
+        return;
+    }
     int remIssue = chunks_of(nxt.t);           // chunks of `nxt` not yet issued
     int remCompute = remIssue;                 // chunks of `cur` not yet multiplied
     bool more = true;                          // is there a chunk left to issue
@@ -1330,7 +1357,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
     }
 }
 
-template <int NW, int RPW>
+template <int NW, int RPW, int NSTAGE>
 int launch_dma(const ConvArgs& a0, hipStream_t s) {
     constexpr int TH = NW * RPW;
     ConvArgs a = a0;
@@ -1347,15 +1374,16 @@ int launch_dma(const ConvArgs& a0, hipStream_t s) {
     if (grid < 8) grid = 8;
     const int tilesPerXcd = (nTiles + 7) / 8;
     constexpr int HALO_INSTR = ((TH + 2) * 34 + 15) / 16;
-    const size_t lds = 2 * (size_t)(HALO_INSTR + 36) * 1024 + NW * 1024 + 512;  // two stages + idle DMA slots' scratch + two bias slots
+    const size_t lds = NSTAGE * (size_t)(HALO_INSTR + 36) * 1024 + NW * 1024 + 512;  // stages + idle DMA slots' scratch + two bias slots
+    if (NSTAGE == 3) FLAIR_CHECK(nTiles <= grid, "flair_conv_nhwc: the three-stage form runs one tile per workgroup");
     static bool attr = false;
     if (!attr) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_dma_kernel<NW, RPW>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_dma_kernel<NW, RPW, NSTAGE>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         FLAIR_CHECK(e == hipSuccess, "flair_conv_nhwc: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr = true;
     }
-    hipLaunchKernelGGL((conv3x3_dma_kernel<NW, RPW>), dim3(grid), dim3(64 * NW), lds, s, a, nTiles, tilesPerXcd);
+    hipLaunchKernelGGL((conv3x3_dma_kernel<NW, RPW, NSTAGE>), dim3(grid), dim3(64 * NW), lds, s, a, nTiles, tilesPerXcd);
     FLAIR_LAUNCH_CHECK();
     return FLAIR_OK;
 }
@@ -1688,9 +1716,9 @@ int dispatch(const ConvArgs& a0, hipStream_t s) {
             return rpw2 ? launch_halo_ks<E, 8, 2, 2>(a, s) : launch_halo_ks<E, 8, 1, 2>(a, s);
         }
         case 7: return launch_halo_ks<E, 4, 1, 2>(a, s);   // (two rows per wave leave 4 waves per CU here: +3.5 ms/step)
-        case 8: return launch_dma<8, 2>(a, s);
-        case 9: return launch_dma<8, 1>(a, s);
-        case 10: return launch_dma<4, 1>(a, s);
+        case 8: return launch_dma<8, 2, 2>(a, s);
+        case 9: return launch_dma<8, 1, 2>(a, s);
+        case 10: return launch_dma<4, 1, 3>(a, s);
         default: return launch_halo<E, 2, 1, 1>(a, s);
     }
 }

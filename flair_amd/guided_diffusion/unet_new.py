@@ -298,13 +298,14 @@ import os as _os
 USE_CHAIN = _os.environ.get("FLAIR_CHAIN", "1") != "0"          # A/B switches for same-box comparisons
 ACT_IN_OFFSET_CONV = _os.environ.get("FLAIR_DCN_ACT", "1") != "0"
 CACHE_FLOW2 = _os.environ.get("FLAIR_FLOW2_CACHE", "1") != "0"
+CHAIN_WIDTHS = (64, 128) if _os.environ.get("FLAIR_CHAIN128", "0") == "1" else (64,)   # c = 128 pairs fused too (A/B switch)
 
 
 def run_trunk(pk, segs, c, *, extra_res=None, out=None, out_scale=1.0):
     """conv3x3+LeakyReLU -> x + conv(relu(conv(x))) [+ extra_res], scaled."""
     k = (1, 3, 3)
     t1 = ops.conv(segs, pk["w0"], pk["b0"], c, k, act=A.ACT_LRELU01)
-    if USE_CHAIN and c == 64 and ops.chain_supported(t1, c):
+    if USE_CHAIN and c in CHAIN_WIDTHS and ops.chain_supported(t1, c):
         return ops.conv_chain(t1, pk["w1"], pk["b1"], A.ACT_RELU, pk["w2"], pk["b2"], A.ACT_NONE, c, c,
                               res0=t1, res1=extra_res, out=out, out_scale=out_scale)
     t2 = ops.conv(t1, pk["w1"], pk["b1"], c, k, act=A.ACT_RELU)
@@ -417,7 +418,7 @@ class BasicVSRPP(nn.Module):
                     if fill is not None:
                         fill.append((flow_n2, flowpad))
                 o = ops.conv([cond_n1, cur, cond_n2, flowpad], pk_a["w0"], pk_a["b0"], c, k3, act=A.ACT_LRELU01)
-                if USE_CHAIN and c == 64 and ops.chain_supported(o, c):
+                if USE_CHAIN and c in CHAIN_WIDTHS and ops.chain_supported(o, c):
                     o = ops.conv_chain(o, pk_a["w2"], pk_a["b2"], A.ACT_LRELU01, pk_a["w4"], pk_a["b4"],
                                        A.ACT_LRELU01, c, c)
                 else:
