@@ -38,7 +38,7 @@ CONV_ROCPROF = {0: "conv_igemm_kernel<{E}, 128, 128, 2, 2>", 1: "conv_igemm_kern
                 2: "conv_igemm_kernel<{E}, 64, 64, 2, 2>", 3: "conv3x3_halo_kernel<{E}, 8, 1, 1>",
                 4: "conv3x3_halo_kernel<{E}, 4, 1, 1>", 5: "conv3x3_halo_kernel<{E}, 2, 1, 1>",
                 6: "conv3x3_halo_ks_kernel<{E}, 8, 1, 2>", 7: "conv3x3_halo_ks_kernel<{E}, 4, 1, 2>",
-                8: "conv3x3_dma_kernel<8, 2>", 9: "conv3x3_dma_kernel<8, 1>", 10: "conv3x3_dma_kernel<4, 1>"}
+                8: "conv3x3_dma_kernel<8, 2, 2>", 9: "conv3x3_dma_kernel<8, 1, 2>", 10: "conv3x3_dma_kernel<4, 1, 3>"}
 CONV_VARIANTS = {0: "conv_igemm_kernel<128co x 128px>", 1: "conv_igemm_kernel<64co x 128px>",
                  2: "conv_igemm_kernel<64co x 64px>", 3: "conv3x3_halo_kernel<8 rows>",
                  4: "conv3x3_halo_kernel<4 rows>", 5: "conv3x3_halo_kernel<2 rows>",
