@@ -1019,9 +1019,10 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
     // (l & 3) ^ swz(row) of that row's pixel / weight row.  Idle slots and out-of-image pixels use an out-of-range offset
     // (the DMA writes zeros: zero padding for free, no branches).
     const int lrow = lane >> 2, lchunk = lane & 3;
-    unsigned hpix[NSLOT];          // halo slots: pixel index inside the frame (0xffffffff: outside); weight slots: unused
-    unsigned woff[NSLOT];          // weight slots: byte offset of the lane's row / chunk inside the packed weights
-    unsigned hchunk[NSLOT];        // halo slots: 16 * logical chunk
+    // A slot is a halo OR a weight instruction (wave-uniformly), so one word serves both: halo slots hold the pixel index
+    // inside the frame (0xffffffff outside the image), weight slots the byte offset of the lane's row / chunk inside the
+    // packed weights (FLAIR_OOB past the last cout); hchunk: 16 * logical chunk of a halo slot (tile independent).
+    unsigned slotv[NSLOT], hchunk[NSLOT];
 #pragma unroll
     for (int i = 0; i < NSLOT; ++i) {
         const int id = wave * NSLOT + i;
@@ -1036,11 +1037,12 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
             const int hr = R / HWP, c = R - hr * HWP;
             const int hh = tl.h0 - 1 + hr, ww = tl.w0 - 1 + c;
             const bool okh = R < HALO_ROWS && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
-            hpix[i] = okh ? (unsigned)(hh * W + ww) : 0xffffffffu;
+            const unsigned hv = okh ? (unsigned)(hh * W + ww) : 0xffffffffu;
             const int row = R - HALO_INSTR * 16;               // tap9 * 64 + co (weight slots)
             const int tap9 = row >> 6, co = row & 63;
             const bool okw = row >= 0 && row < 576 && tl.co0 + co < a.Cout;
-            woff[i] = okw ? (unsigned)(((tl.co0 + co) * taps + tap9) * a.CinTot) * 2u + ((lchunk ^ ((co >> 2) & 3)) << 4) : FLAIR_OOB;
+            const unsigned wv = okw ? (unsigned)(((tl.co0 + co) * taps + tap9) * a.CinTot) * 2u + ((lchunk ^ ((co >> 2) & 3)) << 4) : FLAIR_OOB;
+            slotv[i] = id >= HALO_INSTR ? wv : hv;
         }
     };
 
@@ -1081,8 +1083,9 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
 #pragma unroll
         for (int i = 0; i < NSLOT; ++i) {
             const bool isw = wave * NSLOT + i >= HALO_INSTR;        // wave-uniform
-            const unsigned offh = hpix[i] == 0xffffffffu ? FLAIR_OOB : hpix[i] * ld + cofs + hchunk[i];
-            const unsigned offw = woff[i] == FLAIR_OOB ? FLAIR_OOB : woff[i] + kofs;
+            const unsigned sv = slotv[i];
+            const unsigned offh = sv == 0xffffffffu ? FLAIR_OOB : sv * ld + cofs + hchunk[i];
+            const unsigned offw = sv == FLAIR_OOB ? FLAIR_OOB : sv + kofs;
             u32x4_t d;
             d.x = isw ? wdesc.x : xdesc.x;
             d.y = isw ? wdesc.y : xdesc.y;
@@ -1175,7 +1178,106 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
     // version -- 22 us stores, 12 us bias round trips, the rest instruction issue and instruction-cache misses of eight
     // inlined copies x six activation variants = 14 700 instructions).  Now: one unrolled pass per activation CLASS (chosen
     // by one wave-uniform branch outside), biases from LDS, one 64-bit address per tile and wave, pointer bumps after that.
-    auto epilogue_as = [&](const DmaTile& tl, int biasSlot, auto actTag) {
+    auto epilogue_as = [&](const DmaTile& tl, int biasSlot, auto actTag, auto resTag) {
+        constexpr int ACT = decltype(actTag)::value;       // 0: max(v, slope v)   1: DCN offsets / masks   2: SiLU
+        constexpr bool HASRES = decltype(resTag)::value;   // a residual input exists (its own copy of the code: see below)
+        const float slope = a.act == FLAIR_ACT_NONE ? 1.f : a.act == FLAIR_ACT_RELU ? 0.f : a.act == FLAIR_ACT_LRELU01 ? 0.1f : 0.2f;
+        // Branch-free: every access is a buffer instruction on a wave-uniform descriptor (the wave's first pixel, this tile's
+        // first cout); lanes whose couts are padding use an out-of-range offset (loads deliver 0, stores are dropped).  With
+        // EXEC-masked branches around the loads / stores, hipcc merged its counters at every join into `s_waitcnt vmcnt(0)`:
+        // each residual piece was a serial round trip to memory AND waited for the stores before it (43 us of a 152 us 64 -> 64
+        // convolution with residual).  Now all residual pieces of the wave are requested in one batch up front
+        // (the staging fragments are dead, the registers exist) and the waits are counted; the frame bias is part of the tile's
+        // bias slot in LDS (bias_request).
+        const long p0w = ((long)tl.t * H + tl.h0 + RPW * wave) * W + tl.w0;              // first pixel of the wave's rows (wave-uniform)
+        const int cl = 8 * lh;                                                           // this lane's cout offset inside a 16-cout half
+        const unsigned yLdB = (unsigned)a.yLd * 2u, rLdB = (unsigned)a.res0Ld * 2u;
+        const unsigned span = (unsigned)(RPW * W);                                       // pixels the wave's offsets stay below
+        const __amdgpu_buffer_rsrc_t yd = make_rsrc(reinterpret_cast<char*>(a.y) + (p0w * a.yLd + tl.co0) * 2, span * yLdB);
+        const __amdgpu_buffer_rsrc_t r0d = make_rsrc(reinterpret_cast<const char*>(a.res0) + (a.res0 ? (p0w * a.res0Ld + tl.co0) * 2 : 0),
+                                                     a.res0 ? span * rLdB : 0u);
+        const E* r1b = a.res1 ? reinterpret_cast<const E*>(a.res1) + (p0w + lr) * a.res1Ld + tl.co0 + cl : nullptr;
+        const float* bl = reinterpret_cast<const float*>(smem + BIAS_OFF + (biasSlot & 1) * 256) + cl;
+        const float scale = a.outScale;
+        const unsigned yLane = (unsigned)lr * yLdB + 2u * cl, rLane = (unsigned)lr * rLdB + 2u * cl;
+        // Without a residual no load is issued at all: a load here is younger than the next chunk's DMA pieces, so waiting
+        // for it also waits for those, which otherwise have the whole epilogue left to land (+9 us on a 105 us convolution).
+        uint4 r0v[2][2][RPW];
+        if constexpr (HASRES) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int cofs = i * 32 + 16 * jj;
+                    const bool lane_ok = tl.co0 + cofs + cl < a.Cout;
+#pragma unroll
+                    for (int j = 0; j < RPW; ++j)
+                        r0v[i][jj][j] = buf_load16(r0d, lane_ok ? rLane + (unsigned)(j * W) * rLdB + 2u * cofs : FLAIR_OOB);
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int cofs = i * 32 + 16 * jj;                                       // cout offset of this group inside the tile
+                // (Cout % 8 == 0) lanes whose 8 couts are padding still take part in the v_permlane32_swap below (a swap
+                // under a divergent branch hands the active half garbage); their store offset is out of range
+                const bool lane_ok = tl.co0 + cofs + cl < a.Cout;
+                float bv[8];
+                {
+                    const float4 b0 = *reinterpret_cast<const float4*>(bl + cofs);
+                    const float4 b1 = *reinterpret_cast<const float4*>(bl + cofs + 4);
+                    bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+                }
+#pragma unroll
+                for (int j = 0; j < RPW; ++j) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const auto sw2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[j][i][8 * jj + e]),
+                                                                          __float_as_uint(acc[j][i][8 * jj + 4 + e]), false, false);
+                        v[e] = __uint_as_float(sw2[0]) + bv[e];
+                        v[4 + e] = __uint_as_float(sw2[1]) + bv[4 + e];
+                    }
+                    if constexpr (ACT == 0) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], v[e] * slope);
+                    } else if constexpr (ACT == 1) {
+                        dcn_offset_act<8>(v, tl.co0 + cofs + cl, a.actParam, a.actPeriod);
+                    } else {
+                        // v_rcp_f32 (1 ulp) instead of the IEEE divide of silu_f: ten instructions less per element, and the
+                        // result is rounded to bf16 right below
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] *= __builtin_amdgcn_rcpf(1.f + __expf(-v[e]));
+                    }
+                    if constexpr (HASRES) {
+                        float r[8];
+                        Vec16<E>::load(reinterpret_cast<const E*>(&r0v[i][jj][j]), r);      // zeros without res0 / on padding lanes
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += r[e];
+                        if (r1b && lane_ok) {
+                            Vec16<E>::load(r1b + (long)j * W * a.res1Ld + cofs, r);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] += r[e];
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= scale;
+                    alignas(16) E out[8];
+                    Vec16<E>::store(out, v);
+                    const uint4 ov = *reinterpret_cast<const uint4*>(out);
+                    const unsigned yo = lane_ok ? yLane + (unsigned)(j * W) * yLdB + 2u * cofs : FLAIR_OOB;
+                    if (FLAIR_DBG(a) != 16)
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{ov.x, ov.y, ov.z, ov.w}, yd, (int)yo, 0, 0);
+                    else asm volatile("" ::"v"(ov.x), "v"(ov.y), "v"(ov.z), "v"(ov.w));
+                }
+            }
+    };
+    // One-tile forms (RPW == 1, the per-frame launches): the plain epilogue -- global loads / stores under EXEC-masked
+    // branches.  The buffer-descriptor form below costs these launches ~0.15 us per K chunk (its descriptors raise the
+    // SGPR pressure of the chunk loop: 224 -> 64 at 256^2 26.0 -> 27.0 us, same box), and a per-frame convolution with a
+    // residual is rare on this path (the recurrence's residual blocks are fused chains).
+    auto epilogue_plain_as = [&](const DmaTile& tl, int biasSlot, auto actTag) {
         constexpr int ACT = decltype(actTag)::value;       // 0: max(v, slope v)   1: DCN offsets / masks   2: SiLU
         const float slope = a.act == FLAIR_ACT_NONE ? 1.f : a.act == FLAIR_ACT_RELU ? 0.f : a.act == FLAIR_ACT_LRELU01 ? 0.1f : 0.2f;
         const long p0 = ((long)tl.t * H + tl.h0 + RPW * wave) * W + tl.w0 + lr;          // this lane's pixel in row j = 0
@@ -1183,7 +1285,6 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
         E* yb = reinterpret_cast<E*>(a.y) + p0 * a.yLd + tl.co0 + cl;
         const E* r0b = a.res0 ? reinterpret_cast<const E*>(a.res0) + p0 * a.res0Ld + tl.co0 + cl : nullptr;
         const E* r1b = a.res1 ? reinterpret_cast<const E*>(a.res1) + p0 * a.res1Ld + tl.co0 + cl : nullptr;
-        const float* fbb = a.fbias ? a.fbias + (long)tl.t * a.fbiasLd + tl.co0 + cl : nullptr;
         const float* bl = reinterpret_cast<const float*>(smem + BIAS_OFF + (biasSlot & 1) * 256) + cl;
         const float scale = a.outScale;
 #pragma unroll
@@ -1201,10 +1302,6 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
                     const float4 b0 = *reinterpret_cast<const float4*>(bl + cofs);
                     const float4 b1 = *reinterpret_cast<const float4*>(bl + cofs + 4);
                     bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
-                    if (fbb && lane_ok) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) bv[e] += fbb[cofs + e];
-                    }
                 }
 #pragma unroll
                 for (int j = 0; j < RPW; ++j) {
@@ -1247,9 +1344,33 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
             }
     };
     auto epilogue = [&](const DmaTile& tl, int biasSlot) {
-        if (a.act == FLAIR_ACT_DCN_OFFSETS) epilogue_as(tl, biasSlot, std::integral_constant<int, 1>{});
-        else if (a.act == FLAIR_ACT_SILU) epilogue_as(tl, biasSlot, std::integral_constant<int, 2>{});
-        else epilogue_as(tl, biasSlot, std::integral_constant<int, 0>{});      // NONE / RELU / LeakyReLU (GELU: refused on the host)
+        const bool res = a.res0 || a.res1;
+        auto go = [&](auto actTag) {
+            if constexpr (RPW == 1) {
+                epilogue_plain_as(tl, biasSlot, actTag);
+            } else {
+                if (res) epilogue_as(tl, biasSlot, actTag, std::true_type{});
+                else epilogue_as(tl, biasSlot, actTag, std::false_type{});
+            }
+        };
+        if (a.act == FLAIR_ACT_DCN_OFFSETS) go(std::integral_constant<int, 1>{});
+        else if (a.act == FLAIR_ACT_SILU) go(std::integral_constant<int, 2>{});
+        else go(std::integral_constant<int, 0>{});      // NONE / RELU / LeakyReLU (GELU: refused on the host)
+    };
+    // Residual prefetch: one 4-byte LDS-DMA per output pixel of the wave (64 couts x 2 bytes = the pixel's 128-byte line),
+    // landing in the DMA scratch area, requested BEFORE the DMA pieces of the tile's last chunk: the epilogue's real loads
+    // then find their lines in the L2 instead of paying a trip to HBM with every wave of the CU waiting.  No register
+    // receives data, so nothing can be clobbered; the pieces are older than that chunk's DMA and retire with it.
+    auto prefetch_res = [&](const DmaTile& tl) {
+        const long p0w = ((long)tl.t * H + tl.h0 + RPW * wave) * W + tl.w0;
+        const u32x4_t rd = make_desc(reinterpret_cast<const char*>(a.res0) + (p0w * a.res0Ld + tl.co0) * 2, (unsigned)(RPW * W * a.res0Ld) * 2u);
+        const int j = lane >> 5;
+        const unsigned voff = j < RPW ? (unsigned)((j * W + lr) * a.res0Ld) * 2u : FLAIR_OOB;
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff), "s"((unsigned)(NSTAGE * STAGE_BYTES + wave * 1024)), "s"(rd)
+                     : "memory");
     };
 
     // ---- the (tile, chunk) pipeline.  `cur` is the tile being multiplied, `nxt` the tile whose chunks are being issued.
@@ -1268,6 +1389,10 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
         if (tid < 16) {
             const int bco = tl.co0 + 4 * tid;
             biasReg = (a.bias && bco < a.Cout) ? *reinterpret_cast<const float4*>(a.bias + bco) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.fbias && bco < a.Cout) {            // per-(frame, cout) bias of this tile's frame: folded into the same LDS slot
+                const float* fb = a.fbias + (long)tl.t * a.fbiasLd + bco;
+                biasReg.x += fb[0]; biasReg.y += fb[1]; biasReg.z += fb[2]; biasReg.w += fb[3];
+            }
         }
         biasPending = true;
     };
@@ -1301,6 +1426,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
         if (FLAIR_DBG(a) != 13) epilogue(cur, 0);
         return;
     }
+    const bool res0any = a.res0 || a.res1;
     int remIssue = chunks_of(nxt.t);           // chunks of `nxt` not yet issued
     int remCompute = remIssue;                 // chunks of `cur` not yet multiplied
     bool more = true;                          // is there a chunk left to issue
@@ -1324,6 +1450,8 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
                 bias_request(nxt);
             }
         }
+        if constexpr (RPW == 2)
+            if (remCompute == 1 && a.res0 && FLAIR_DBG(a) != 19) prefetch_res(cur);
         if (more) {
             if (FLAIR_DBG(a) != 12) issue(nxt, wk, stage ^ 1);     // (timing switches: 11 no MFMA phase, 12 no DMA, 13 no epilogue)
             walk_next(nxt.t, wk);
@@ -1335,8 +1463,10 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
         if (--remCompute == 0) {
             if (FLAIR_DBG(a) != 13) {
                 epilogue(cur, iCur);
-                // a tile whose 64 couts all exist issues exactly 4 * RPW store instructions per wave, after this iteration's DMA
-                storesInFlight = cur.co0 + 64 <= a.Cout && FLAIR_DBG(a) != 14;
+                // every tile issues exactly 4 * RPW store instructions per wave as its youngest memory operations (a second
+                // residual is loaded under a branch, where hipcc places its own waits: not counted on)
+                // (RPW == 2: padding lanes' stores are issued too, out of range; RPW == 1: full tiles without a residual branch)
+                storesInFlight = (RPW == 2 ? !a.res1 : cur.co0 + 64 <= a.Cout && !res0any) && FLAIR_DBG(a) != 14 && FLAIR_DBG(a) != 16;
             }
             ++iCur;
             if (!tile_at(iCur, cur)) break;
@@ -1798,6 +1928,11 @@ extern "C" int flair_conv_nhwc(const flair_conv_params* p, const void* const* x,
     a.fbias = frame_bias;
     a.fbiasLd = p->frame_bias_ld;
     FLAIR_CHECK(!frame_bias || p->frame_bias_ld >= p->Cout, "flair_conv_nhwc: frame_bias_ld");
+    {   // the halo / LDS-DMA epilogues address one frame of y / res0 / res1 through buffer descriptors with 32-bit byte offsets
+        const unsigned long long hw = (unsigned long long)p->H * p->W * esz;
+        FLAIR_CHECK(hw * p->y_ld < 0x40000000ull && (!res0 || hw * p->res_ld[0] < 0x40000000ull) && (!res1 || hw * p->res_ld[1] < 0x40000000ull),
+                    "flair_conv_nhwc: one frame of the output / a residual spans more than 1 GiB");
+    }
     a.res0 = res0;
     a.res1 = res1;
     a.res0Ld = p->res_ld[0];

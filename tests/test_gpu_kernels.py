@@ -92,6 +92,36 @@ def test_conv(dev, dtype, case):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", [
+    # T, H, W, cin, cout, kernel, nres: per-(frame, cout) bias (the ResBlock's emb term, unet_new.py:258-264,321) on the
+    # LDS-DMA kernel (persistent and one-tile forms, with and without a residual, padded cout tile), the K-split and the igemm kernels
+    (4, 128, 128, 64, 128, (1, 3, 3), 0), (4, 128, 128, 64, 128, (3, 3, 3), 1), (3, 256, 256, 32, 72, (1, 3, 3), 1),
+    (1, 256, 256, 64, 64, (1, 3, 3), 0), (1, 128, 128, 128, 128, (1, 3, 3), 1), (5, 16, 16, 64, 64, (1, 3, 3), 0),
+])
+def test_conv_frame_bias(dev, dtype, case):
+    ops = _ops()
+    T, H, W, cin, cout, k, nres = case
+    g = torch.Generator().manual_seed(T * 31 + H + cout)
+    x = rb(torch.randn(T, cin, H, W, generator=g), dtype)
+    w = rb(torch.randn(cout, cin, *k, generator=g) / math.sqrt(cin * k[0] * 9), dtype)
+    b = torch.randn(cout, generator=g) * 0.1
+    fb = torch.randn(T, cout, generator=g)
+    res = [rb(torch.randn(T, cout, H, W, generator=g), dtype) for _ in range(nres)]
+    if k[0] == 1:
+        ref = F.conv2d(x, w[:, :, 0], b, padding=1)
+    else:
+        ref = F.conv3d(x.permute(1, 0, 2, 3)[None], w, b, padding=1)[0].permute(1, 0, 2, 3)
+    ref = ref + fb[:, :, None, None]
+    for r in res:
+        ref = ref + r
+    wp = ops.pack_conv_weight(w, [(cin, cin)], dtype).to(dev)
+    y = ops.conv([to_clip(x, dtype, dev)], wp, b.to(dev), cout, k, frame_bias=fb.to(dev),
+                 res0=to_clip(res[0], dtype, dev) if res else None)
+    torch.cuda.synchronize()
+    assert_close(from_clip(y), ref, dtype, f"conv frame_bias {case}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [
     # T, H, W, segs (None: no stage A), c_mid, coutB, actA, actB, nres
     (1, 256, 256, [64], 64, 64, 2, 2, 0),              # conv_offset[2]+[4] at the 256^2 level (8 x 32 tiles)
     (1, 128, 128, [128], 128, 128, 1, 0, 2),           # ResidualBlockNoBN at the 128^2 level (8 x 8 tiles)

@@ -1,4 +1,5 @@
 """Micro-benchmark of the conv kernel on the shapes of one UNet forward (config 2)."""
+import os
 import sys
 import torch
 from flair_amd import ops
@@ -42,7 +43,14 @@ def main():
         taps = k[0] * k[1] * k[2]
         w = (torch.randn(cout, taps, cin, device=dev) / (taps * cin) ** 0.5).to(dt)
         b = torch.randn(cout, device=dev)
-        y = ops.conv(xs, w, b, cout, k)
+        # FLAIR_BENCH_RES=1: with a residual input (ResBlock conv2), =2: with a per-frame bias (ResBlock conv1: emb)
+        mode = int(os.environ.get("FLAIR_BENCH_RES", "0"))
+        kw = {}
+        if mode == 1:
+            kw["res0"] = torch.randn(T, H, W, cout, device=dev).to(dt)
+        if mode == 2:
+            kw["frame_bias"] = torch.randn(T, cout, device=dev)
+        y = ops.conv(xs, w, b, cout, k, **kw)
         torch.cuda.synchronize()
         n = 10
         # replayed from a hipGraph: an eager python loop cannot issue launches faster than ~15 us apart
@@ -52,7 +60,7 @@ def main():
         with torch.cuda.stream(side):
             with torch.cuda.graph(g, stream=side):
                 for _ in range(n):
-                    ops.conv(xs, w, b, cout, k, out=y)
+                    ops.conv(xs, w, b, cout, k, out=y, **kw)
         g.replay()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
