@@ -405,6 +405,53 @@ __global__ __launch_bounds__(32 * NPF * TPP, (NCF >= 4 ? 32 * NPF * TPP / 256 : 
         }
     }
     E* y = reinterpret_cast<E*>(a.y);
+    if constexpr (sizeof(E) == 2) {
+        // bf16, Cout % 8 == 0 and 16-byte aligned rows: the biases of all the wave's store groups are requested in one batch
+        // (buffer loads: zero-sized descriptor without a bias, out-of-range offset past Cout -- loaded per element under
+        // branches, every group of four was a serial round trip that also waited for the store before it), and
+        // v_permlane32_swap pairs give each lane 8 consecutive couts of its pixel: 16-byte stores, half as many.
+        if ((a.Cout & 7) == 0 && (a.yLd & 7) == 0 && (reinterpret_cast<uintptr_t>(a.y) & 15) == 0) {
+            const __amdgpu_buffer_rsrc_t bd = make_rsrc(a.bias, a.bias ? (unsigned)a.Cout * 4u : 0u);
+            const __amdgpu_buffer_rsrc_t yd = make_rsrc(a.y, (unsigned)a.P * a.yLd * 2u);      // < 2 GiB: host check
+#pragma unroll
+            for (int i = 0; i < PAIRS; ++i) {
+                const int pair = KSPLIT > 1 ? wave % NPAIR : wave * PAIRS + i;
+                const int pfrag = pair % NPF, cf = pair / NPF;
+                const long po = p0 + pfrag * 32 + lr;              // lanes l and l + 32 share the pixel: the swaps pair lanes with equal predicates
+                uint4 bq[2][2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int co = cf * 32 + 16 * j + 8 * lh;
+                    bq[j][0] = buf_load16(bd, co < a.Cout ? 4u * co : FLAIR_OOB);
+                    bq[j][1] = buf_load16(bd, co < a.Cout ? 4u * co + 16u : FLAIR_OOB);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int co = cf * 32 + 16 * j + 8 * lh;
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const auto sw2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][8 * j + e]),
+                                                                          __float_as_uint(acc[i][8 * j + 4 + e]), false, false);
+                        v[e] = __uint_as_float(sw2[0]);
+                        v[4 + e] = __uint_as_float(sw2[1]);
+                    }
+                    v[0] += __uint_as_float(bq[j][0].x); v[1] += __uint_as_float(bq[j][0].y);
+                    v[2] += __uint_as_float(bq[j][0].z); v[3] += __uint_as_float(bq[j][0].w);
+                    v[4] += __uint_as_float(bq[j][1].x); v[5] += __uint_as_float(bq[j][1].y);
+                    v[6] += __uint_as_float(bq[j][1].z); v[7] += __uint_as_float(bq[j][1].w);
+                    alignas(16) E out[8];
+                    Vec16<E>::store(out, v);
+                    const uint4 ov = *reinterpret_cast<const uint4*>(out);
+                    // (a buffer store with an out-of-range offset for tail pixels / padding couts: under an EXEC-masked branch
+                    // hipcc waits for the previous store's acknowledgement at the join)
+                    const unsigned yo = po < a.P && co < a.Cout ? ((unsigned)po * a.yLd + co) * 2u : FLAIR_OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{ov.x, ov.y, ov.z, ov.w}, yd, (int)yo, 0, 0);
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < PAIRS; ++i) {
         const int pair = KSPLIT > 1 ? wave % NPAIR : wave * PAIRS + i;
@@ -491,7 +538,8 @@ extern "C" int flair_dcn_align(const flair_dcn_params* p, const void* x0, const 
     const unsigned long long b0 = ((unsigned long long)(a.P - 1) * p->x_ld[0] + half) * esz;
     const unsigned long long b1 = ((unsigned long long)(a.P - 1) * p->x_ld[1] + half) * esz;
     const unsigned long long br = ((unsigned long long)(a.P - 1) * p->raw_ld + 27 * p->G) * esz;
-    FLAIR_CHECK(b0 < 0x80000000ull && b1 < 0x80000000ull && br < 0x80000000ull, "flair_dcn_align: tensor spans >= 2 GiB");
+    const unsigned long long by = (unsigned long long)a.P * p->y_ld * esz;
+    FLAIR_CHECK(b0 < 0x80000000ull && b1 < 0x80000000ull && br < 0x80000000ull && by < 0x80000000ull, "flair_dcn_align: tensor spans >= 2 GiB");
     FLAIR_CHECK(a.P + 2l * p->W + 2 < (1l << 23) && (long)p->x_ld[0] * esz < (1l << 23) && (long)p->x_ld[1] * esz < (1l << 23),
                 "flair_dcn_align: F*H*W = %ld pixels (limit 2^23 per call: call per frame)", a.P);
     a.xBytes[0] = (unsigned)b0; a.xBytes[1] = (unsigned)b1; a.rawBytes = (unsigned)((br + 15) / 16 * 16);
