@@ -15,10 +15,15 @@
 namespace {
 
 // PyTorch's grid_sample round trip: pixel -> [-1,1] -> pixel (align_corners=True).
+// The result passes through an empty asm: `ix - floor(ix)` must see the ROUNDED coordinate like the reference does, and under
+// -ffp-contract=fast whether hipcc fuses the last multiply into that subtraction depends on the code around the inlined call --
+// two kernels that must agree bit for bit, vsrpp_prep and vsrpp_warp2, came out one ulp apart in their weights.
 __device__ __forceinline__ float gs_coord(float pix, int size) {
     const float denom = (float)(size > 1 ? size - 1 : 1);
     const float g = 2.0f * pix / denom - 1.0f;
-    return ((g + 1.f) / 2.f) * (float)(size - 1);
+    float r = ((g + 1.f) / 2.f) * (float)(size - 1);
+    asm("" : "+v"(r));
+    return r;
 }
 
 template <typename E>
@@ -27,6 +32,7 @@ __global__ void flow_warp_kernel(const E* x, int xLd, const float* flow, int fLd
     constexpr int VEC = ET<E>::VEC;
     const int cv = C / VEC;
     const long total = (long)F * H * W * cv;
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(x, (unsigned)((size_t)F * H * W * xLd * sizeof(E)));     // < 2 GiB: host check
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c0 = (int)(i % cv) * VEC;
         const long p = i / cv;
@@ -44,19 +50,24 @@ __global__ void flow_warp_kernel(const E* x, int xLd, const float* flow, int fLd
         const int x0 = (int)fx, y0 = (int)fy;
         const float ax = ix - fx, ay = iy - fy;
         const float wgt[4] = {(1.f - ax) * (1.f - ay), ax * (1.f - ay), (1.f - ax) * ay, ax * ay};
-        float acc[VEC];
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
-        const E* fb = x + f * H * W * xLd + c0;
+        // all four corner loads in flight at once: a whole-clip descriptor, out-of-range offset for corners outside the frame
+        // (behind `if (inside)` branches every load was followed by its own `s_waitcnt vmcnt(0)`)
+        uint4 cq[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int xx = x0 + (q & 1), yy = y0 + (q >> 1);
-            if ((unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H) {
-                float v[VEC];
-                Vec16<E>::load(fb + ((long)yy * W + xx) * xLd, v);
+            const bool in = (unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H;
+            cq[q] = buf_load16(xr, in ? (unsigned)(((f * H + yy) * W + xx) * xLd + c0) * (unsigned)sizeof(E) : FLAIR_OOB);
+        }
+        float acc[VEC];
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) acc[k] = fmaf(wgt[q], v[k], acc[k]);
-            }
+        for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v[VEC];
+            Vec16<E>::load(reinterpret_cast<const E*>(&cq[q]), v);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[k] = fmaf(wgt[q], v[k], acc[k]);
         }
         Vec16<E>::store(y + p * yLd + c0, acc);
     }
@@ -185,28 +196,37 @@ __global__ void vsrpp_warp2_kernel(const E* prop, int propLd, const E* feat2, in
     const float* flow = second ? flow2 : flow1;
     E* dst = second ? cond2 : cond1;
     const int dstLd = second ? cond2Ld : cond1Ld;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c0 = (int)(i % cv) * VEC;
-        const long p = i / cv;
-        const int w = (int)(p % W), h = (int)(p / W);
-        const float2 f = *reinterpret_cast<const float2*>(flow + p * 2);
+    // The four corners are unconditional buffer loads on a descriptor of the source frame (corners outside the image get an
+    // out-of-range offset and read 0, which adds nothing): as plain loads under `if (inside)` branches hipcc followed each
+    // one with `s_waitcnt vmcnt(0)` -- four serial round trips to memory per pixel in a kernel that is nothing but latency.
+    const __amdgpu_buffer_rsrc_t sr = make_rsrc(src, (unsigned)((size_t)H * W * srcLd * sizeof(E)));
+    // (32-bit index arithmetic: one frame has < 2^31 pieces, and 64-bit division is a loop on this hardware)
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total; i += gridDim.x * blockDim.x) {
+        const unsigned p = i / (unsigned)cv;
+        const int c0 = (int)(i - p * (unsigned)cv) * VEC;
+        const int h = (int)(p / (unsigned)W), w = (int)(p - (unsigned)h * (unsigned)W);
+        const float2 f = *reinterpret_cast<const float2*>(flow + (size_t)p * 2);
         int xy[2];
         float wg[4];
         bil_setup((float)w + f.x, (float)h + f.y, W, H, xy, wg);
+        uint4 cq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int xx = xy[0] + (q & 1), yy = xy[1] + (q >> 1);
+            const bool in = (unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H;
+            cq[q] = buf_load16(sr, in ? (unsigned)((yy * W + xx) * srcLd + c0) * (unsigned)sizeof(E) : FLAIR_OOB);
+        }
         float acc[VEC];
 #pragma unroll
         for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int xx = xy[0] + (q & 1), yy = xy[1] + (q >> 1);
-            if ((unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H) {
-                float v[VEC];
-                Vec16<E>::load(src + ((long)yy * W + xx) * srcLd + c0, v);
+            float v[VEC];
+            Vec16<E>::load(reinterpret_cast<const E*>(&cq[q]), v);
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) acc[k] = fmaf(wg[q], v[k], acc[k]);
-            }
+            for (int k = 0; k < VEC; ++k) acc[k] = fmaf(wg[q], v[k], acc[k]);
         }
-        Vec16<E>::store(dst + p * dstLd + c0, acc);
+        Vec16<E>::store(dst + (size_t)p * dstLd + c0, acc);
     }
 }
 
@@ -312,6 +332,8 @@ extern "C" int flair_flow_warp(const void* x, int dtype, int x_ld, const float* 
                                int W, int C, int border, void* y, int y_ld, hipStream_t stream) {
     FLAIR_CHECK(x && flow && y && F > 0 && H > 0 && W > 0 && C > 0 && flow_ld >= 2 && flow_ld % 2 == 0,
                 "flair_flow_warp: bad argument");
+    FLAIR_CHECK((unsigned long long)F * H * W * x_ld * (dtype == FLAIR_BF16 ? 2 : 4) < 0x80000000ull,
+                "flair_flow_warp: the source clip spans >= 2 GiB (32-bit gather offsets): call per frame");
     if (dtype == FLAIR_BF16) {
         FLAIR_CHECK(C % 8 == 0 && x_ld % 8 == 0 && y_ld % 8 == 0, "flair_flow_warp: bf16 needs C %% 8 == 0");
         hipLaunchKernelGGL(flow_warp_kernel<bf16_t>, dim3(grid_for((long)F * H * W * (C / 8))), dim3(256), 0, stream,
@@ -376,6 +398,8 @@ extern "C" int flair_vsrpp_warp2(const void* prop, int prop_ld, const void* feat
     const int vec = dtype == FLAIR_BF16 ? 8 : 4;
     FLAIR_CHECK(dtype == FLAIR_BF16 || dtype == FLAIR_F32, "flair_vsrpp_warp2: bad dtype");
     FLAIR_CHECK(C % vec == 0, "flair_vsrpp_warp2: C %% %d", vec);
+    FLAIR_CHECK((unsigned long long)H * W * prop_ld * (16 / vec) < 0x80000000ull && (unsigned long long)H * W * feat2_ld * (16 / vec) < 0x80000000ull,
+                "flair_vsrpp_warp2: a source frame spans >= 2 GiB");
     const dim3 grid(grid_for((long)H * W * (C / vec)), flow2 ? 2 : 1);
     if (dtype == FLAIR_BF16)
         hipLaunchKernelGGL(vsrpp_warp2_kernel<bf16_t>, grid, dim3(256), 0, stream, (const bf16_t*)prop, prop_ld,

@@ -299,6 +299,54 @@ def test_flow_warp(dev, dtype, border):
     assert_close(from_clip(y), ref, dtype, "flow_warp", scale=4.0)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("second", [False, True])
+def test_vsrpp_warp2(dev, dtype, second):
+    """The two warps of one propagation step in one launch (flair_vsrpp_warp2; unet_new.py:706,719 = mmedit flow_warp with
+    zeros padding) against the oracle, with flows that push whole regions outside the frame and strided output views."""
+    from oracle.thirdparty import flow_warp
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    H, W, C = 20, 24, 64
+    prop = rb(torch.randn(1, C, H, W, generator=g), dtype)
+    feat2 = rb(torch.randn(1, C, H, W, generator=g), dtype)
+    f1 = torch.randn(1, H, W, 2, generator=g) * 4.0
+    f2 = torch.randn(1, H, W, 2, generator=g) * 9.0
+    f1[:, :3] += 30.0                                  # rows whose four corners all fall outside
+    tdt = torch.bfloat16 if dtype == torch.bfloat16 else torch.float32
+    buf = torch.zeros(1, H, W, 3 * C, device=dev, dtype=tdt)      # cond1 | (gap) | cond2 as views of one wider clip tensor
+    c1, c2 = buf[..., :C], buf[..., 2 * C:]
+    ops.vsrpp_warp2(to_clip(prop, dtype, dev), to_clip(feat2, dtype, dev) if second else None, f1.to(dev),
+                    f2.to(dev) if second else None, c1, c2 if second else None)
+    torch.cuda.synchronize()
+    assert_close(from_clip(c1), flow_warp(prop, f1, padding_mode="zeros"), dtype, "vsrpp_warp2 cond1", scale=4.0)
+    if second:
+        assert_close(from_clip(c2), flow_warp(feat2, f2, padding_mode="zeros"), dtype, "vsrpp_warp2 cond2", scale=4.0)
+    assert buf[..., C:2 * C].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_vsrpp_prep_and_warp2_agree_bit_for_bit(dev, dtype):
+    """The first forward of a clip composes the second-order flow and warps in flair_vsrpp_prep, every later one warps with
+    the cached flow in flair_vsrpp_warp2: a replayed hipGraph equals the eager first call only if the two kernels round
+    identically (they once differed by an FMA contraction in the bilinear weights)."""
+    ops = _ops()
+    tdt = torch.bfloat16 if dtype == torch.bfloat16 else torch.float32
+    g = torch.Generator().manual_seed(5)
+    for H, W, C in ((32, 32, 64), (20, 24, 128)):
+        prop = torch.randn(1, H, W, C, generator=g).to(dev).to(tdt)
+        feat2 = torch.randn(1, H, W, C, generator=g).to(dev).to(tdt)
+        f1 = (torch.randn(1, H, W, 2, generator=g) * 3).to(dev)
+        fprev = (torch.randn(1, H, W, 2, generator=g) * 3).to(dev)
+        c1, c2, f2 = torch.empty_like(prop), torch.empty_like(prop), torch.empty_like(f1)
+        pad = torch.zeros(1, H, W, 32, device=dev, dtype=tdt)
+        ops.vsrpp_prep(prop, feat2, f1, fprev, c1, c2, f2, pad)
+        d1, d2 = torch.empty_like(prop), torch.empty_like(prop)
+        ops.vsrpp_warp2(prop, feat2, f1, f2, d1, d2)
+        torch.cuda.synchronize()
+        assert torch.equal(c1, d1) and torch.equal(c2, d2)
+
+
 def test_flow_compose(dev):
     from oracle.thirdparty import flow_warp
     ops = _ops()
