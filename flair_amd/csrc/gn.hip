@@ -21,6 +21,8 @@
 //                 raw input in the same pass.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -155,7 +157,7 @@ struct GnApply {
 };
 
 template <typename E>
-__global__ void gn_apply_kernel(GnApply a) {
+__global__ __launch_bounds__(512) void gn_apply_kernel(GnApply a) {
     prefetch_kernargs<sizeof(GnApply)>();
     constexpr int VEC = ET<E>::VEC;
     const int cv = a.C / VEC;
@@ -172,109 +174,144 @@ __global__ void gn_apply_kernel(GnApply a) {
         base = reinterpret_cast<const E*>(a.s.x[1]) + (c0 - a.s.c[0]);
         ld = a.s.ld[1];
     }
-    // fold normalisation + affine + FiLM into y = x*A + B
+    // fold normalisation + affine + FiLM into y = x*A + B.  All parameter loads of the thread's VEC channels are issued
+    // before the first use (statistics, gamma, beta; then, under ONE uniform branch, the FiLM row): written channel by channel
+    // with the `if (film)` inside, every channel was two serial round trips to the L2 -- 16 of them before a workgroup
+    // touched its first pixel, on a pass that lasts ~40 us.
     float A[VEC], B[VEC];
     const int cpg = a.C / a.groups;
     const int stat = f / a.framesPerStat;
+    {
+        float2 st[VEC];
+        float gm[VEC], bt[VEC], sc[VEC], sh[VEC];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-        const int c = c0 + i;
-        const int g = c / cpg;
-        const float mean = a.stats[(stat * a.groups + g) * 2], rstd = a.stats[(stat * a.groups + g) * 2 + 1];
-        float ga = a.gamma[c] * rstd;
-        float be = a.beta[c] - mean * ga;
+        for (int i = 0; i < VEC; ++i) {
+            const int c = c0 + i;
+            st[i] = *reinterpret_cast<const float2*>(a.stats + (stat * a.groups + c / cpg) * 2);
+            gm[i] = a.gamma[c];
+            bt[i] = a.beta[c];
+            sc[i] = 0.f;
+            sh[i] = 0.f;
+        }
         if (a.film) {
-            const float sc = 1.f + a.film[(long)f * a.filmLd + c];
-            const float sh = a.film[(long)f * a.filmLd + a.C + c];
-            ga *= sc;
-            be = be * sc + sh;
-        }
-        A[i] = ga;
-        B[i] = be;
-    }
-    E* y = reinterpret_cast<E*>(a.y);
-    E* raw = reinterpret_cast<E*>(a.raw);
-    const long fin = (long)f * a.H * a.W;
-    if (a.resample == 0) {
-        const long n = (long)a.H * a.W;
-        const long per = (n + a.blocksPerFrame - 1) / a.blocksPerFrame;
-        long end = (blk + 1) * per;
-        if (end > n) end = n;
-        // y never aliases x (header contract): keep 4 loads in flight before the first store
-        long p = blk * per + r;
-        for (; p + 3 * rows < end; p += 4 * rows) {
-            uint4 raw4[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                raw4[u] = *reinterpret_cast<const uint4*>(base + (fin + p + (long)u * rows) * ld);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                float v[VEC];
-                Vec16<E>::load(reinterpret_cast<const E*>(&raw4[u]), v);
-#pragma unroll
-                for (int i = 0; i < VEC; ++i) v[i] = apply_act(fmaf(v[i], A[i], B[i]), a.act);
-                Vec16<E>::store(y + (fin + p + (long)u * rows) * a.yLd + c0, v);
-            }
-        }
-        for (; p < end; p += rows) {
-            float v[VEC];
-            Vec16<E>::load(base + (fin + p) * ld, v);
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) v[i] = apply_act(fmaf(v[i], A[i], B[i]), a.act);
-            Vec16<E>::store(y + (fin + p) * a.yLd + c0, v);
-        }
-    } else if (a.resample == 1) {
-        const int Ho = a.H / 2, Wo = a.W / 2;
-        const long n = (long)Ho * Wo;
-        const long per = (n + a.blocksPerFrame - 1) / a.blocksPerFrame;
-        long end = (blk + 1) * per;
-        if (end > n) end = n;
-        const long fout = (long)f * n;
-        for (long p = blk * per + r; p < end; p += rows) {
-            const int ho = (int)(p / Wo), wo = (int)(p % Wo);
-            float accv[VEC], accr[VEC];
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) accv[i] = accr[i] = 0.f;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const long pi = fin + (long)(2 * ho + (q >> 1)) * a.W + 2 * wo + (q & 1);
-                float v[VEC];
-                Vec16<E>::load(base + pi * ld, v);
-#pragma unroll
-                for (int i = 0; i < VEC; ++i) {
-                    accr[i] += v[i];
-                    accv[i] += apply_act(fmaf(v[i], A[i], B[i]), a.act);
-                }
-            }
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
-                accv[i] *= 0.25f;
-                accr[i] *= 0.25f;
+                sc[i] = a.film[(long)f * a.filmLd + c0 + i];
+                sh[i] = a.film[(long)f * a.filmLd + a.C + c0 + i];
             }
-            Vec16<E>::store(y + (fout + p) * a.yLd + c0, accv);
-            if (raw) Vec16<E>::store(raw + (fout + p) * a.rawLd + c0, accr);
         }
-    } else {
-        const long n = (long)a.H * a.W;
-        const long per = (n + a.blocksPerFrame - 1) / a.blocksPerFrame;
-        long end = (blk + 1) * per;
-        if (end > n) end = n;
-        const int Wo = a.W * 2;
-        const long fout = (long)f * n * 4;
-        for (long p = blk * per + r; p < end; p += rows) {
-            const int h = (int)(p / a.W), w = (int)(p % a.W);
-            float v[VEC], u[VEC];
-            Vec16<E>::load(base + (fin + p) * ld, u);
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) v[i] = apply_act(fmaf(u[i], A[i], B[i]), a.act);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const long po = fout + (long)(2 * h + (q >> 1)) * Wo + 2 * w + (q & 1);
-                Vec16<E>::store(y + po * a.yLd + c0, v);
-                if (raw) Vec16<E>::store(raw + po * a.rawLd + c0, u);
+        for (int i = 0; i < VEC; ++i) {
+            float ga = gm[i] * st[i].y;
+            float be = bt[i] - st[i].x * ga;
+            if (a.film) {
+                const float m = 1.f + sc[i];
+                ga *= m;
+                be = be * m + sh[i];
             }
+            A[i] = ga;
+            B[i] = be;
         }
     }
+    // The streaming loops are compiled once per activation CLASS (none / SiLU / anything else), chosen by one wave-uniform
+    // branch: with apply_act's switch inside them the kernel was 12 400 instructions with a branch per element, and SiLU's IEEE
+    // divide (ten instructions) made the pass VALU-bound next to its HBM time; bf16 outputs take v_rcp_f32 (1 ulp) instead.
+    auto run = [&](auto actTag) {
+        constexpr int ACTC = decltype(actTag)::value;
+        auto act1 = [&](float x) -> float {
+            if constexpr (ACTC == 0) return x;
+            else if constexpr (ACTC == 1) {
+                if constexpr (sizeof(E) == 2) return x * __builtin_amdgcn_rcpf(1.f + __expf(-x));
+                else return silu_f(x);
+            } else return apply_act(x, a.act);
+        };
+        E* y = reinterpret_cast<E*>(a.y);
+        E* raw = reinterpret_cast<E*>(a.raw);
+        const long fin = (long)f * a.H * a.W;
+        if (a.resample == 0) {
+            const long n = (long)a.H * a.W;
+            const long per = (n + a.blocksPerFrame - 1) / a.blocksPerFrame;
+            long end = (blk + 1) * per;
+            if (end > n) end = n;
+            // y never aliases x (header contract): keep 4 loads in flight before the first store
+            long p = blk * per + r;
+            for (; p + 3 * rows < end; p += 4 * rows) {
+                uint4 raw4[4];
+    #pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    raw4[u] = *reinterpret_cast<const uint4*>(base + (fin + p + (long)u * rows) * ld);
+    #pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float v[VEC];
+                    Vec16<E>::load(reinterpret_cast<const E*>(&raw4[u]), v);
+    #pragma unroll
+                    for (int i = 0; i < VEC; ++i) v[i] = act1(fmaf(v[i], A[i], B[i]));
+                    Vec16<E>::store(y + (fin + p + (long)u * rows) * a.yLd + c0, v);
+                }
+            }
+            for (; p < end; p += rows) {
+                float v[VEC];
+                Vec16<E>::load(base + (fin + p) * ld, v);
+    #pragma unroll
+                for (int i = 0; i < VEC; ++i) v[i] = act1(fmaf(v[i], A[i], B[i]));
+                Vec16<E>::store(y + (fin + p) * a.yLd + c0, v);
+            }
+        } else if (a.resample == 1) {
+            const int Ho = a.H / 2, Wo = a.W / 2;
+            const long n = (long)Ho * Wo;
+            const long per = (n + a.blocksPerFrame - 1) / a.blocksPerFrame;
+            long end = (blk + 1) * per;
+            if (end > n) end = n;
+            const long fout = (long)f * n;
+            for (long p = blk * per + r; p < end; p += rows) {
+                const int ho = (int)(p / Wo), wo = (int)(p % Wo);
+                float accv[VEC], accr[VEC];
+    #pragma unroll
+                for (int i = 0; i < VEC; ++i) accv[i] = accr[i] = 0.f;
+    #pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const long pi = fin + (long)(2 * ho + (q >> 1)) * a.W + 2 * wo + (q & 1);
+                    float v[VEC];
+                    Vec16<E>::load(base + pi * ld, v);
+    #pragma unroll
+                    for (int i = 0; i < VEC; ++i) {
+                        accr[i] += v[i];
+                        accv[i] += act1(fmaf(v[i], A[i], B[i]));
+                    }
+                }
+    #pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    accv[i] *= 0.25f;
+                    accr[i] *= 0.25f;
+                }
+                Vec16<E>::store(y + (fout + p) * a.yLd + c0, accv);
+                if (raw) Vec16<E>::store(raw + (fout + p) * a.rawLd + c0, accr);
+            }
+        } else {
+            const long n = (long)a.H * a.W;
+            const long per = (n + a.blocksPerFrame - 1) / a.blocksPerFrame;
+            long end = (blk + 1) * per;
+            if (end > n) end = n;
+            const int Wo = a.W * 2;
+            const long fout = (long)f * n * 4;
+            for (long p = blk * per + r; p < end; p += rows) {
+                const int h = (int)(p / a.W), w = (int)(p % a.W);
+                float v[VEC], u[VEC];
+                Vec16<E>::load(base + (fin + p) * ld, u);
+    #pragma unroll
+                for (int i = 0; i < VEC; ++i) v[i] = act1(fmaf(u[i], A[i], B[i]));
+    #pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const long po = fout + (long)(2 * h + (q >> 1)) * Wo + 2 * w + (q & 1);
+                    Vec16<E>::store(y + po * a.yLd + c0, v);
+                    if (raw) Vec16<E>::store(raw + po * a.rawLd + c0, u);
+                }
+            }
+        }
+    };
+    if (a.act == FLAIR_ACT_NONE) run(std::integral_constant<int, 0>{});
+    else if (a.act == FLAIR_ACT_SILU) run(std::integral_constant<int, 1>{});
+    else run(std::integral_constant<int, 2>{});
 }
 
 // ---- small tensors: the whole norm in ONE launch, one workgroup per (statistic, group) ------------------
@@ -450,7 +487,7 @@ extern "C" int flair_groupnorm_nhwc(const flair_gn_params* p, const void* x0, co
     FLAIR_CHECK(p->resample >= 0 && p->resample <= 2, "flair_groupnorm_nhwc: resample mode");
     FLAIR_CHECK(p->resample != 1 || (p->H % 2 == 0 && p->W % 2 == 0), "flair_groupnorm_nhwc: odd size for pooling");
     const int cv = C / vec;
-    FLAIR_CHECK(cv <= 1024, "flair_groupnorm_nhwc: C=%d too wide", C);
+    FLAIR_CHECK(cv <= 512, "flair_groupnorm_nhwc: C=%d too wide", C);
     const int rows = cv <= 256 ? 256 / cv : 1;      // wide tensors: one pixel row per workgroup of cv threads
     const int threads = rows * cv;
     const int nstat = p->F / p->frames_per_stat;
