@@ -1744,13 +1744,28 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 // split-K reduce: sum the f32 partials, then the usual epilogue
 template <typename E>
 __global__ void conv_splitk_reduce_kernel(ConvArgs a) {
-    const long quads = a.P * (a.Cout / 4);
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < quads; i += (long)gridDim.x * blockDim.x) {
-        const long p = i / (a.Cout / 4);
-        const int co = (int)(i % (a.Cout / 4)) * 4;
+    // (split-K runs on small launches only: P * Cout / 4 < 2^31, so 32-bit index arithmetic -- 64-bit division is a loop
+    // here; four partials in flight per thread, summed in slice order so that the result does not depend on the batching)
+    const unsigned cq = (unsigned)(a.Cout / 4);
+    const unsigned quads = (unsigned)a.P * cq;
+    const size_t slice = (size_t)a.P * a.Cout;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += gridDim.x * blockDim.x) {
+        const unsigned p = i / cq;
+        const int co = (int)(i - p * cq) * 4;
+        const float* src = a.part + (size_t)p * a.Cout + co;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int k = 0; k < a.splitK; ++k) {
-            const float4 v = *reinterpret_cast<const float4*>(a.part + ((long)k * a.P + p) * a.Cout + co);
+        int k = 0;
+        for (; k + 4 <= a.splitK; k += 4) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(src + (size_t)(k + u) * slice);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w;
+            }
+        }
+        for (; k < a.splitK; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)k * slice);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
         store_quad<E>(a, p, co, s.x, s.y, s.z, s.w);

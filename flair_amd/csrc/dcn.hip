@@ -162,9 +162,7 @@ __global__ __launch_bounds__(32 * NPF * TPP, (NCF >= 4 ? 32 * NPF * TPP / 256 : 
     // phase of a K step, where the consumed gather registers are dead, so it adds nothing to
     // the register peak; the mapping is recomputed per tap (once every cbPerTap steps).
     const __amdgpu_buffer_rsrc_t rr = make_rsrc(a.raw, a.rawBytes);
-    auto stage_raw = [&](int tap) {
-        uint4 reg[RAWR];
-        int dst[RAWR];
+    auto raw_issue = [&](int tap, uint4 (&reg)[RAWR]) {
 #pragma unroll
         for (int j = 0; j < RAWR; ++j) {
             const int id = tid + j * NT;
@@ -172,11 +170,20 @@ __global__ __launch_bounds__(32 * NPF * TPP, (NCF >= 4 ? 32 * NPF * TPP / 256 : 
             const long pp = p0 + px;
             const unsigned within = (unsigned)(3 * tap * G) * ESZ + pc * 16;
             reg[j] = buf_load16(rr, px < TP && pp < a.P ? (unsigned)(pp * a.rawLd * ESZ) + within : FLAIR_OOB);
-            dst[j] = px < TP ? ((tap & 1) * TP + px) * rawPitch + pc * 16 : -1;
         }
+    };
+    auto raw_write = [&](int tap, const uint4 (&reg)[RAWR]) {
 #pragma unroll
-        for (int j = 0; j < RAWR; ++j)
-            if (dst[j] >= 0) *reinterpret_cast<uint4*>(sraw + dst[j]) = reg[j];
+        for (int j = 0; j < RAWR; ++j) {
+            const int id = tid + j * NT;
+            const int px = id / slabPieces, pc = id - px * slabPieces;
+            if (px < TP) *reinterpret_cast<uint4*>(sraw + ((tap & 1) * TP + px) * rawPitch + pc * 16) = reg[j];
+        }
+    };
+    auto stage_raw = [&](int tap) {
+        uint4 reg[RAWR];
+        raw_issue(tap, reg);
+        raw_write(tap, reg);
     };
 
     const int cpg = a.Cin / G;
@@ -336,7 +343,15 @@ __global__ __launch_bounds__(32 * NPF * TPP, (NCF >= 4 ? 32 * NPF * TPP / 256 : 
     // (the issue for the first step of tap T, at the top of step T*cbPerTap - (PFD-1)).
     constexpr int LEAD = PFD + 1;
     int stageTap = 0;
-    while (stageTap < 2 && stageTap * cbPerTap - LEAD < 0) stage_raw(stageTap++);      // taps 0 (and 1) before the loop
+    {   // taps 0 (and 1) before the loop: both requests in flight before either is written (one round trip, not two)
+        uint4 r0[RAWR], r1[RAWR];
+        const bool two = cbPerTap - LEAD < 0;
+        raw_issue(0, r0);
+        if (two) raw_issue(1, r1);
+        raw_write(0, r0);
+        if (two) raw_write(1, r1);
+        stageTap = two ? 2 : 1;
+    }
     int stageAt = stageTap * cbPerTap - LEAD;
     __syncthreads();
     auto mfma_step = [&](int buf) {
