@@ -409,45 +409,69 @@ __global__ __launch_bounds__(1024) void gn_group_kernel(GnApply a, float eps) {
     }
     E* y = reinterpret_cast<E*>(a.y);
     const int hw = a.H * a.W;
-    auto apply = [&](const uint4& raw, long p) {
-        float v[VEC], A[VEC], B[VEC];
-        Vec16<E>::load(reinterpret_cast<const E*>(&raw), v);
-        if (a.film) {
-            const float* fr = a.film + (p / hw) * a.filmLd + c0;
+    // FiLM rows of a pixel's frame: requested for TWO of the thread's pixels before either is finished (one load round trip
+    // per pair instead of one per pixel; these launches are a few microseconds long), activation per class as in gn_apply
+    auto film_load = [&](long p, float (&sc)[VEC], float (&sh)[VEC]) {
+        const float* fr = a.film + (p / hw) * a.filmLd + c0;
 #pragma unroll
-            for (int e = 0; e < VEC; e += 4) {
-                float s4[4], h4[4];
-                if (a.filmVec) {
-                    const float4 sc = *reinterpret_cast<const float4*>(fr + e);
-                    const float4 sh = *reinterpret_cast<const float4*>(fr + a.C + e);
-                    s4[0] = sc.x; s4[1] = sc.y; s4[2] = sc.z; s4[3] = sc.w;
-                    h4[0] = sh.x; h4[1] = sh.y; h4[2] = sh.z; h4[3] = sh.w;
-                } else {
+        for (int e = 0; e < VEC; e += 4) {
+            if (a.filmVec) {
+                const float4 s4 = *reinterpret_cast<const float4*>(fr + e);
+                const float4 h4 = *reinterpret_cast<const float4*>(fr + a.C + e);
+                sc[e] = s4.x; sc[e + 1] = s4.y; sc[e + 2] = s4.z; sc[e + 3] = s4.w;
+                sh[e] = h4.x; sh[e + 1] = h4.y; sh[e + 2] = h4.z; sh[e + 3] = h4.w;
+            } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        s4[j] = fr[e + j];
-                        h4[j] = fr[a.C + e + j];
-                    }
+                for (int jx = 0; jx < 4; ++jx) {
+                    sc[e + jx] = fr[e + jx];
+                    sh[e + jx] = fr[a.C + e + jx];
                 }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float m = 1.f + s4[j];
-                    A[e + j] = ga[e + j] * m;
-                    B[e + j] = be[e + j] * m + h4[j];
-                }
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                A[e] = ga[e];
-                B[e] = be[e];
             }
         }
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) v[e] = apply_act(fmaf(v[e], A[e], B[e]), a.act);
-        Vec16<E>::store(y + p * a.yLd + c0, v);
     };
-    for (q = threadIdx.x / pp; q < pixPerStat; q += rows) apply(cache[q * pp + k], pix0 + q);
+    auto run = [&](auto actTag) {
+        constexpr int ACTC = decltype(actTag)::value;
+        auto act1 = [&](float x) -> float {
+            if constexpr (ACTC == 0) return x;
+            else if constexpr (ACTC == 1) {
+                if constexpr (sizeof(E) == 2) return x * __builtin_amdgcn_rcpf(1.f + __expf(-x));
+                else return silu_f(x);
+            } else return apply_act(x, a.act);
+        };
+        auto finish = [&](const uint4& raw, long p, const float (&sc)[VEC], const float (&sh)[VEC]) {
+            float v[VEC];
+            Vec16<E>::load(reinterpret_cast<const E*>(&raw), v);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                float A = ga[e], B = be[e];
+                if (a.film) {
+                    const float m = 1.f + sc[e];
+                    A *= m;
+                    B = B * m + sh[e];
+                }
+                v[e] = act1(fmaf(v[e], A, B));
+            }
+            Vec16<E>::store(y + p * a.yLd + c0, v);
+        };
+        long qq = threadIdx.x / pp;
+        for (; qq + rows < pixPerStat; qq += 2 * rows) {
+            float sc0[VEC] = {}, sh0[VEC] = {}, sc1[VEC] = {}, sh1[VEC] = {};
+            if (a.film) {
+                film_load(pix0 + qq, sc0, sh0);
+                film_load(pix0 + qq + rows, sc1, sh1);
+            }
+            finish(cache[qq * pp + k], pix0 + qq, sc0, sh0);
+            finish(cache[(qq + rows) * pp + k], pix0 + qq + rows, sc1, sh1);
+        }
+        for (; qq < pixPerStat; qq += rows) {
+            float sc0[VEC] = {}, sh0[VEC] = {};
+            if (a.film) film_load(pix0 + qq, sc0, sh0);
+            finish(cache[qq * pp + k], pix0 + qq, sc0, sh0);
+        }
+    };
+    if (a.act == FLAIR_ACT_NONE) run(std::integral_constant<int, 0>{});
+    else if (a.act == FLAIR_ACT_SILU) run(std::integral_constant<int, 1>{});
+    else run(std::integral_constant<int, 2>{});
 }
 
 }  // namespace
