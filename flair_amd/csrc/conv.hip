@@ -174,76 +174,116 @@ __device__ __forceinline__ void store_quad(const ConvArgs& a, long p, int co, fl
     }
 }
 
-// Epilogue of one 32 (couts) x 32 (pixels) accumulator fragment, low instruction count form (Cout % 8 == 0): after
-// v_permlane32_swap a lane holds 8 consecutive couts of its pixel per 16-cout half, so bias / residuals / output move as
-// 16-byte (bf16) or 2 x 16-byte (f32) pieces, and the activation is compiled for ONE class (ACT: 0 max(v, slope v) =
-// none / ReLU / LeakyReLU, 1 DCN offsets and masks, 2 SiLU, 3 exact GELU), chosen by one wave-uniform branch at the call
-// site.  store_quad above (8-byte pieces, six activation variants inlined per quad) made conv_igemm_kernel<128,128> 77 KB of
-// code, more than the instruction cache that two CUs share.  All lanes must call this (the swaps cross the half-waves).
-template <typename E, int ACT>
-__device__ __forceinline__ void store_frag32(const ConvArgs& a, const f32x16& c, long p, int co32, bool pvalid, int lh) {
+// Epilogue of one wave's FC x FP accumulator fragments (32 couts x 32 pixels each), Cout % 8 == 0: after v_permlane32_swap a lane
+// holds 8 consecutive couts of its pixel per 16-cout half, so bias / residuals / output move as 16-byte (bf16) or 2 x 16-byte
+// (f32) pieces, and the activation is compiled for ONE class (ACT: 0 max(v, slope v) = none / ReLU / LeakyReLU, 1 DCN offsets and
+// masks, 2 SiLU, 3 exact GELU), chosen by one wave-uniform branch at the call site (store_quad above -- 8-byte pieces, six
+// activation variants inlined per quad -- made conv_igemm_kernel<128,128> 77 KB of code, more than the instruction cache that
+// two CUs share).  Branch-free memory access: buffer descriptors based at the wave's first pixel / first cout, an out-of-range
+// offset on lanes past P or Cout; per fragment, the bias, frame-bias and residual pieces of both halves are requested in one batch.  With the loads and stores under `if (pvalid && co < Cout)` hipcc put `s_waitcnt vmcnt(0)` behind every
+// one: each 16-cout half was a bias round trip that also waited for the previous half's store -- on the 1x1 128 -> 64 convolution
+// of 16 x 256^2 the epilogue was 60 us of 110 (profiles/r03_dma_switches.txt, r3k).  All lanes must call this (the swaps cross
+// the half-waves).
+template <typename E, int ACT, int FC, int FP>
+__device__ __forceinline__ void igemm_epilogue(const ConvArgs& a, const f32x16 (&acc)[FC][FP], long pbase, int cobase, int lr, int lh) {
+    constexpr unsigned ESZ = sizeof(E);
+    constexpr int VEC = ET<E>::VEC, NV = 8 / VEC;               // 16-byte pieces per 8 couts: 1 (bf16) or 2 (f32)
     const float slope = a.act == FLAIR_ACT_NONE ? 1.f : a.act == FLAIR_ACT_RELU ? 0.f : a.act == FLAIR_ACT_LRELU01 ? 0.1f : 0.2f;
+    const unsigned yLdB = (unsigned)a.yLd * ESZ, r0LdB = (unsigned)a.res0Ld * ESZ, r1LdB = (unsigned)a.res1Ld * ESZ;
+    constexpr unsigned SPAN = FP * 32;                           // pixels the wave's offsets stay below
+    const __amdgpu_buffer_rsrc_t yd = make_rsrc(reinterpret_cast<char*>(a.y) + ((size_t)pbase * a.yLd + cobase) * ESZ, SPAN * yLdB);
+    const __amdgpu_buffer_rsrc_t r0d = make_rsrc(reinterpret_cast<const char*>(a.res0) + (a.res0 ? ((size_t)pbase * a.res0Ld + cobase) * ESZ : 0),
+                                                 a.res0 ? SPAN * r0LdB : 0u);
+    const __amdgpu_buffer_rsrc_t r1d = make_rsrc(reinterpret_cast<const char*>(a.res1) + (a.res1 ? ((size_t)pbase * a.res1Ld + cobase) * ESZ : 0),
+                                                 a.res1 ? SPAN * r1LdB : 0u);
+    const int coLeft = a.Cout - cobase;                          // couts of the tensor from the wave's first one on (may be <= 0)
+    const __amdgpu_buffer_rsrc_t bd = make_rsrc(a.bias ? a.bias + cobase : nullptr, a.bias && coLeft > 0 ? (unsigned)coLeft * 4u : 0u);
+    const long hw = (long)a.H * a.W;
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-        if (co32 + 16 * jj >= a.Cout) continue;                  // wave-uniform
-        float v[8];
+    for (int j = 0; j < FP; ++j) {
+        const long p = pbase + j * 32 + lr;
+        const bool pvalid = p < a.P;
+        const unsigned pl = (unsigned)(j * 32 + lr);
+        const float* fbrow = a.fbias ? a.fbias + (pvalid ? p / hw : 0) * a.fbiasLd + cobase : nullptr;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const auto sw2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(c[8 * jj + e]), __float_as_uint(c[8 * jj + 4 + e]), false, false);
-            v[e] = __uint_as_float(sw2[0]);
-            v[4 + e] = __uint_as_float(sw2[1]);
-        }
-        const int co = co32 + 16 * jj + 8 * lh;
-        if (!pvalid || co >= a.Cout) continue;
-        if (a.bias) {
-            const float4 b0 = *reinterpret_cast<const float4*>(a.bias + co);
-            const float4 b1 = *reinterpret_cast<const float4*>(a.bias + co + 4);
-            v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-            v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-        }
-        if (a.fbias) {
-            const float* fb = a.fbias + (p / ((long)a.H * a.W)) * a.fbiasLd + co;
+        for (int i = 0; i < FC; ++i) {
+            // every load of this fragment (two 16-cout halves) is requested before the first use: one round trip per fragment
+            uint4 bq[2][2], r0v[2][NV], r1v[2][NV], fq[2][2];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += fb[e];
-        }
-        if constexpr (ACT == 0) {
+            for (int jj = 0; jj < 2; ++jj) {
+                const int cw = i * 32 + 16 * jj + 8 * lh;
+                const bool ok = pvalid && cw < coLeft;
+                bq[jj][0] = buf_load16(bd, 4u * (unsigned)cw);              // (past Cout: outside the descriptor, reads 0)
+                bq[jj][1] = buf_load16(bd, 4u * (unsigned)cw + 16u);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], v[e] * slope);
-        } else if constexpr (ACT == 1) {
-            dcn_offset_act<8>(v, co, a.actParam, a.actPeriod);
-        } else if constexpr (ACT == 2) {
+                for (int q = 0; q < NV; ++q) {
+                    r0v[jj][q] = buf_load16(r0d, ok ? pl * r0LdB + (unsigned)(cw + q * VEC) * ESZ : FLAIR_OOB);
+                    r1v[jj][q] = buf_load16(r1d, ok ? pl * r1LdB + (unsigned)(cw + q * VEC) * ESZ : FLAIR_OOB);
+                }
+                fq[jj][0] = fq[jj][1] = make_uint4(0u, 0u, 0u, 0u);
+            }
+            if (a.fbias) {                                       // wave-uniform; clamped in-range address on padding lanes
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
-        } else {
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int cw = i * 32 + 16 * jj + 8 * lh;
+                    const float* fp = fbrow + (cw < coLeft ? cw : 0);
+                    fq[jj][0] = *reinterpret_cast<const uint4*>(fp);
+                    fq[jj][1] = *reinterpret_cast<const uint4*>(fp + 4);
+                }
+            }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752f));
-        }
-        constexpr int VEC = ET<E>::VEC;                          // 8 (bf16: one 16-byte piece) or 4 (f32: two)
-        if (a.res0) {
-            const E* r = reinterpret_cast<const E*>(a.res0) + p * a.res0Ld + co;
+            for (int jj = 0; jj < 2; ++jj) {
+                const f32x16& c = acc[i][j];
+                float v[8];
 #pragma unroll
-            for (int q = 0; q < 8; q += VEC) {
-                float t[VEC];
-                Vec16<E>::load(r + q, t);
+                for (int e = 0; e < 4; ++e) {
+                    const auto sw2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(c[8 * jj + e]), __float_as_uint(c[8 * jj + 4 + e]), false, false);
+                    v[e] = __uint_as_float(sw2[0]);
+                    v[4 + e] = __uint_as_float(sw2[1]);
+                }
+                const int cw = i * 32 + 16 * jj + 8 * lh;
+                const bool ok = pvalid && cw < coLeft;
+                {
+                    const uint4 b0 = bq[jj][0], b1 = bq[jj][1], f0 = fq[jj][0], f1 = fq[jj][1];
+                    v[0] += __uint_as_float(b0.x) + __uint_as_float(f0.x); v[1] += __uint_as_float(b0.y) + __uint_as_float(f0.y);
+                    v[2] += __uint_as_float(b0.z) + __uint_as_float(f0.z); v[3] += __uint_as_float(b0.w) + __uint_as_float(f0.w);
+                    v[4] += __uint_as_float(b1.x) + __uint_as_float(f1.x); v[5] += __uint_as_float(b1.y) + __uint_as_float(f1.y);
+                    v[6] += __uint_as_float(b1.z) + __uint_as_float(f1.z); v[7] += __uint_as_float(b1.w) + __uint_as_float(f1.w);
+                }
+                if constexpr (ACT == 0) {
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) v[q + e] += t[e];
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], v[e] * slope);
+                } else if constexpr (ACT == 1) {
+                    dcn_offset_act<8>(v, cobase + cw, a.actParam, a.actPeriod);
+                } else if constexpr (ACT == 2) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752f));
+                }
+#pragma unroll
+                for (int q = 0; q < NV; ++q) {
+                    float t[VEC];
+                    Vec16<E>::load(reinterpret_cast<const E*>(&r0v[jj][q]), t);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) v[q * VEC + e] += t[e];
+                    Vec16<E>::load(reinterpret_cast<const E*>(&r1v[jj][q]), t);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) v[q * VEC + e] += t[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= a.outScale;
+#pragma unroll
+                for (int q = 0; q < NV; ++q) {
+                    alignas(16) E out[VEC];
+                    Vec16<E>::store(out, v + q * VEC);
+                    const uint4 ov = *reinterpret_cast<const uint4*>(out);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{ov.x, ov.y, ov.z, ov.w}, yd,
+                                                           (int)(ok ? pl * yLdB + (unsigned)(cw + q * VEC) * ESZ : FLAIR_OOB), 0, 0);
+                }
             }
         }
-        if (a.res1) {
-            const E* r = reinterpret_cast<const E*>(a.res1) + p * a.res1Ld + co;
-#pragma unroll
-            for (int q = 0; q < 8; q += VEC) {
-                float t[VEC];
-                Vec16<E>::load(r + q, t);
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) v[q + e] += t[e];
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= a.outScale;
-        E* dst = reinterpret_cast<E*>(a.y) + p * a.yLd + co;
-#pragma unroll
-        for (int q = 0; q < 8; q += VEC) Vec16<E>::store(dst + q, v + q);
     }
 }
 
@@ -1519,7 +1559,10 @@ int launch_dma(const ConvArgs& a0, hipStream_t s) {
 }
 
 // TC x TP block tile (couts x pixels), 4 waves arranged WC x WP.
-template <typename E, int TC, int TP, int WC, int WP>
+// PD = K steps whose operands are in flight in registers ahead of the step being multiplied.  One K step is 8 MFMAs per wave
+// (64 x 64 tile: 2), far less than one round trip to the L2 / HBM, so with PD = 1 (rounds 1-2) every step lasted one load
+// latency: 1x1 256 -> 128 on 16 x 128^2 ran at 1.7 TB/s, the deep-K 3x3x3 convolutions of the 16^2 .. 4^2 levels at ~0.7 us per step.
+template <typename E, int TC, int TP, int WC, int WP, int PD>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     prefetch_kernargs<sizeof(ConvArgs)>();
     constexpr int BKE = Mma<E>::BKE;
@@ -1535,7 +1578,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     constexpr int BUF = (TC + TP) * 64;
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform: the epilogue builds buffer descriptors from it)
     const int wc = wave / WP, wp = wave % WP;
 
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -1565,7 +1608,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const int tFirst = (int)(p0 / ((long)a.H * a.W));                       // frame of the tile's first pixel
     const int tileFrames = (int)((TP + (long)a.H * a.W - 1) / ((long)a.H * a.W)) + 1;   // frames one tile can span
 
-    uint4 xreg[XR], wreg[WR];
+    uint4 xreg[PD][XR], wreg[PD][WR];
 
     // K-loop state (block uniform); with split-K, blockIdx.y owns steps [ks0, ks1)
     const int nkAll = taps * (a.CinTot / BKE);
@@ -1581,7 +1624,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 
     const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.w, a.wBytes);
     constexpr unsigned ESZ = sizeof(E);
-    auto issue_loads = [&]() {
+    auto issue_loads = [&](int set) {
         // buffer resource = the frames this pixel tile can touch for the current temporal tap,
         // starting at frame fb (a whole clip may exceed the 2 GiB one resource can address)
         const int ld = a.segLd[seg];
@@ -1604,13 +1647,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             const bool ok = xvalid[i] && (unsigned)t2 < (unsigned)a.T && (unsigned)h2 < (unsigned)a.Hin &&
                             (unsigned)w2 < (unsigned)a.Win;
             const unsigned off = ok ? (unsigned)((((t2 - fb) * a.Hin + h2) * a.Win + w2) * ld + coff) * ESZ : FLAIR_OOB;
-            xreg[i] = buf_load16(xr, off);
+            xreg[set][i] = buf_load16(xr, off);
         }
         const unsigned kofs = (unsigned)(tap * a.CinTot + segOff + coff) * ESZ;
 #pragma unroll
         for (int j = 0; j < WR; ++j) {
             const int n = co0 + srow + 64 * j;
-            wreg[j] = buf_load16(wrs, n < a.Cout ? (unsigned)(n * taps * a.CinTot) * ESZ + kofs : FLAIR_OOB);
+            wreg[set][j] = buf_load16(wrs, n < a.Cout ? (unsigned)(n * taps * a.CinTot) * ESZ + kofs : FLAIR_OOB);
         }
     };
     auto advance = [&]() {
@@ -1635,14 +1678,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             }
         }
     };
-    auto write_lds = [&](int buf) {
+    auto write_lds = [&](int buf, int set) {
         char* base = smem + buf * BUF;
 #pragma unroll
         for (int j = 0; j < WR; ++j)
-            *reinterpret_cast<uint4*>(base + lds_off(srow + 64 * j, chunk)) = wreg[j];
+            *reinterpret_cast<uint4*>(base + lds_off(srow + 64 * j, chunk)) = wreg[set][j];
 #pragma unroll
         for (int i = 0; i < XR; ++i)
-            *reinterpret_cast<uint4*>(base + TC * 64 + lds_off(srow + 64 * i, chunk)) = xreg[i];
+            *reinterpret_cast<uint4*>(base + TC * 64 + lds_off(srow + 64 * i, chunk)) = xreg[set][i];
     };
 
     f32x16 acc[FC][FP];
@@ -1656,41 +1699,59 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const int nk = ks1 - ks0;
     const int lr = lane & 31, lh = lane >> 5;
 
-    issue_loads();
-    advance();
-    write_lds(0);
-    __syncthreads();
-
-    for (int ks = 0; ks < nk; ++ks) {
-        const int cur = ks & 1;
-        const bool more = ks + 1 < nk;
-        if (more) {
-            issue_loads();
+    // register set u holds step k with k % PD == u: issued PD steps before it is written to LDS (one step before it is multiplied)
+#pragma unroll
+    for (int u = 0; u < PD; ++u)
+        if (u < nk) {
+            issue_loads(u);
             advance();
         }
-        const char* wb = smem + cur * BUF;
-        const char* xb = wb + TC * 64;
-        uint4 af[FC][2], bfr[FP][2];
+    write_lds(0, 0);
+    __syncthreads();
+
+    for (int ks = 0; ks < nk; ks += PD) {
 #pragma unroll
-        for (int i = 0; i < FC; ++i) {
-            const int row = wc * (TC / WC) + i * 32 + lr;
-            af[i][0] = *reinterpret_cast<const uint4*>(wb + lds_off(row, Mma<E>::chunk(0, lh)));
-            af[i][1] = *reinterpret_cast<const uint4*>(wb + lds_off(row, Mma<E>::chunk(1, lh)));
-        }
+        for (int u = 0; u < PD; ++u) {
+            const int k = ks + u;
+            if (k >= nk) break;                     // block uniform
+            const int cur = k & 1;
+            if (k + PD < nk) {                      // set u went to LDS in the previous step: free for step k + PD
+                if (FLAIR_DBG(a) != 32) issue_loads(u);
+                advance();
+            }
+            const char* wb = smem + cur * BUF;
+            const char* xb = wb + TC * 64;
+            uint4 af[FC][2], bfr[FP][2];
 #pragma unroll
-        for (int j = 0; j < FP; ++j) {
-            const int row = wp * (TP / WP) + j * 32 + lr;
-            bfr[j][0] = *reinterpret_cast<const uint4*>(xb + lds_off(row, Mma<E>::chunk(0, lh)));
-            bfr[j][1] = *reinterpret_cast<const uint4*>(xb + lds_off(row, Mma<E>::chunk(1, lh)));
+            for (int i = 0; i < FC; ++i) {
+                const int row = wc * (TC / WC) + i * 32 + lr;
+                af[i][0] = *reinterpret_cast<const uint4*>(wb + lds_off(row, Mma<E>::chunk(0, lh)));
+                af[i][1] = *reinterpret_cast<const uint4*>(wb + lds_off(row, Mma<E>::chunk(1, lh)));
+            }
+#pragma unroll
+            for (int j = 0; j < FP; ++j) {
+                const int row = wp * (TP / WP) + j * 32 + lr;
+                bfr[j][0] = *reinterpret_cast<const uint4*>(xb + lds_off(row, Mma<E>::chunk(0, lh)));
+                bfr[j][1] = *reinterpret_cast<const uint4*>(xb + lds_off(row, Mma<E>::chunk(1, lh)));
+            }
+#pragma unroll
+            for (int i = 0; i < FC; ++i)
+#pragma unroll
+                for (int j = 0; j < FP; ++j) Mma<E>::run(af[i], bfr[j], acc[i][j]);
+            if (k + 1 < nk) write_lds(cur ^ 1, (u + 1) % PD);
+            __syncthreads();
         }
+    }
+
+    if (FLAIR_DBG(a) == 31) {                   // (timing switches of the diagnostic build: 31 no epilogue, 32 no loads past the first steps)
 #pragma unroll
         for (int i = 0; i < FC; ++i)
 #pragma unroll
-            for (int j = 0; j < FP; ++j) Mma<E>::run(af[i], bfr[j], acc[i][j]);
-        if (more) write_lds(cur ^ 1);
-        __syncthreads();
+            for (int j = 0; j < FP; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[i][j][r]));     // keep the K loop alive
+        return;
     }
-
     // ---- epilogue: lane = pixel column, register quad = 4 consecutive couts ----
     if (a.splitK > 1) {   // raw f32 partials; bias/act/residual happen in the reduce kernel
 #pragma unroll
@@ -1714,13 +1775,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         (!a.res0 || (((uintptr_t)a.res0 & 15) == 0 && (a.res0Ld * (int)sizeof(E)) % 16 == 0)) &&
         (!a.res1 || (((uintptr_t)a.res1 & 15) == 0 && (a.res1Ld * (int)sizeof(E)) % 16 == 0))) {
         auto run = [&](auto actTag) {
-            constexpr int ACT = decltype(actTag)::value;
-#pragma unroll
-            for (int j = 0; j < FP; ++j) {
-                const long p = p0 + wp * (TP / WP) + j * 32 + lr;
-#pragma unroll
-                for (int i = 0; i < FC; ++i) store_frag32<E, ACT>(a, acc[i][j], p, co0 + wc * (TC / WC) + i * 32, p < a.P, lh);
-            }
+            igemm_epilogue<E, decltype(actTag)::value, FC, FP>(a, acc, p0 + wp * (TP / WP), co0 + wc * (TC / WC), lr, lh);
         };
         if (a.act == FLAIR_ACT_DCN_OFFSETS) run(std::integral_constant<int, 1>{});
         else if (a.act == FLAIR_ACT_SILU) run(std::integral_constant<int, 2>{});
@@ -1772,14 +1827,14 @@ __global__ void conv_splitk_reduce_kernel(ConvArgs a) {
     }
 }
 
-template <typename E, int TC, int TP, int WC, int WP>
-int launch(const ConvArgs& a0, hipStream_t s) {
+template <typename E, int TC, int TP, int WC, int WP, int PD>
+int launch_pd(const ConvArgs& a0, hipStream_t s) {
     ConvArgs a = a0;
     a.nPixTiles = cdiv(a.P, TP);
     a.nCoTiles = cdiv(a.Cout, TC);
     const int grid = a.nPixTiles * a.nCoTiles;
     const size_t lds = 2 * (TC + TP) * 64;
-    hipLaunchKernelGGL((conv_igemm_kernel<E, TC, TP, WC, WP>), dim3(grid, a.splitK), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<E, TC, TP, WC, WP, PD>), dim3(grid, a.splitK), dim3(256), lds, s, a);
     FLAIR_LAUNCH_CHECK();
     if (a.splitK > 1) {
         long g = (a.P * (a.Cout / 4) + 255) / 256;
@@ -1788,6 +1843,13 @@ int launch(const ConvArgs& a0, hipStream_t s) {
         FLAIR_LAUNCH_CHECK();
     }
     return FLAIR_OK;
+}
+
+// FLAIR_IGEMM_PD = 1 selects the one-step-ahead form of rounds 1-2 (A/B switch), default 4 steps in flight
+template <typename E, int TC, int TP, int WC, int WP>
+int launch(const ConvArgs& a, hipStream_t s) {
+    static const int pd = getenv("FLAIR_IGEMM_PD") ? atoi(getenv("FLAIR_IGEMM_PD")) : 4;
+    return pd <= 1 ? launch_pd<E, TC, TP, WC, WP, 1>(a, s) : launch_pd<E, TC, TP, WC, WP, 4>(a, s);
 }
 
 // Split-K factor for the im2col path: deep-K convolutions on few pixels (the 16x16 .. 4x4
