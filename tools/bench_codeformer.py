@@ -45,7 +45,7 @@ def main():
         torch.cuda.synchronize()
         prof, ops.PROFILE = ops.PROFILE, None
         fam = {}
-        for f, _dt, flops, nbytes, e0, e1 in prof:
+        for f, _dt, flops, nbytes, e0, e1, *_rest in prof:
             d = fam.setdefault(f[0], [0, 0.0, 0.0, 0.0])
             d[0] += 1
             d[1] += flops
