@@ -14,8 +14,10 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof /tmp/pmc_fetch /tmp/pmc_write
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/prof -o p --output-format csv -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_profiled_steps6.json 2>/dev/null
 cp /tmp/prof/p_kernel_stats.csv $OUT/bench_steps6_kernel_stats.csv
-FLAIR_BENCH_REPLAY=off timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pmc_fetch -o b --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-FLAIR_BENCH_REPLAY=off timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pmc_write -o b --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+# HBM traffic of the dominant kernel: its shapes launched as often as one step launches them and nothing else (the whole bench under
+# counter collection serialises ~10 000 launches and did not finish within the box's silence limit on two of three boxes)
+timeout -k 10 150 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pmc_fetch -o b --output-format csv -- python $R/tools/pmc_dominant.py $OUT/bench_full.json > /dev/null 2>&1
+timeout -k 10 150 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pmc_write -o b --output-format csv -- python $R/tools/pmc_dominant.py $OUT/bench_full.json > /dev/null 2>&1
 python $R/tools/pmc_traffic.py /tmp/pmc_fetch /tmp/pmc_write $OUT/hbm_traffic_pmc.json > $OUT/hbm_traffic_pmc.txt
 cd $R
 timeout -k 10 300 python bench.py --task x8_bicubic --no-cpu-baseline > $OUT/bench_x8_bicubic.json 2>/dev/null

@@ -31,8 +31,8 @@ def load(d, cname):
 
 def main():
     f, w = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
-    print("# rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- "
-          "python bench.py --steps 2 --warmup 1 --no-cpu-baseline")
+    cmd = sys.argv[4] if len(sys.argv) > 4 else "python tools/pmc_dominant.py <bench line>  (each shape of the dominant kernel as often as one step launches it)"
+    print("# rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- " + cmd)
     print("# HBM bytes per launch = FETCH_SIZE*1024*2 (gfx950 reports half of a wide coalesced read, "
           "MI355X_MICROARCH.md) + WRITE_SIZE*1024")
     rows = []
@@ -50,7 +50,7 @@ def main():
     if len(sys.argv) > 3:   # machine-readable copy (bench.py fills roofline.traffic from it)
         import json
         with open(sys.argv[3], "w") as fh:
-            json.dump({"command": "python bench.py --steps 2 --warmup 1 --no-cpu-baseline",
+            json.dump({"command": cmd,
                        "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes; "
                                  "read = FETCH_SIZE*1024*2 (gfx950 correction), write = WRITE_SIZE*1024",
                        "kernels": {k: {"launches": calls, "read_bytes_per_launch": fe, "write_bytes_per_launch": wr,
