@@ -1562,20 +1562,29 @@ int launch_dma(const ConvArgs& a0, hipStream_t s) {
 // PD = K steps whose operands are in flight in registers ahead of the step being multiplied.  One K step is 8 MFMAs per wave
 // (64 x 64 tile: 2), far less than one round trip to the L2 / HBM, so with PD = 1 (rounds 1-2) every step lasted one load
 // latency: 1x1 256 -> 128 on 16 x 128^2 ran at 1.7 TB/s, the deep-K 3x3x3 convolutions of the 16^2 .. 4^2 levels at ~0.7 us per step.
-template <typename E, int TC, int TP, int WC, int WP, int PD>
+// KWID = 2 (bf16, every input segment a multiple of 64 channels): one K step = 64 channels = 128-byte LDS rows, so a staging load
+// instruction covers 8 rows x 128 bytes (whole cache lines) instead of 16 rows x 64 bytes.  The 64-byte form keeps the texture
+// addresser busy ~38 cycles per 1 KB instruction where whole lines take about half (profiles/r03_igemm_1x1_pmc.txt: TA busy 75 us
+// of the 108 us 1x1 128 -> 64 convolution on 16 x 256^2), and half as many barriers per K.
+template <typename E, int TC, int TP, int WC, int WP, int PD, int KWID>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     prefetch_kernargs<sizeof(ConvArgs)>();
-    constexpr int BKE = Mma<E>::BKE;
+    constexpr int BKE = Mma<E>::BKE * KWID;
+    constexpr int ROWB = 64 * KWID;                // bytes per LDS row (one K step of one cout / pixel)
+    constexpr int CPR = 4 * KWID;                  // 16-byte chunks per row
+    constexpr int RPP = 256 / CPR;                 // rows staged per pass of the 256 threads
     constexpr int VEC = ET<E>::VEC;
     constexpr int FC = TC / WC / 32;  // 32x32 fragments per wave along cout
     constexpr int FP = TP / WP / 32;  // ... along pixels
-    constexpr int XR = TP / 64;       // activation rows staged per thread
-    constexpr int WR = TC / 64;       // weight rows staged per thread
+    constexpr int XR = TP / RPP;      // activation rows staged per thread
+    constexpr int WR = TC / RPP;      // weight rows staged per thread
     static_assert(WC * WP == 4 && FC >= 1 && FP >= 1 && XR >= 1 && WR >= 1, "tile");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // layout: [buf][ W tile (TC rows) | X tile (TP rows) ], 64-byte rows
-    constexpr int BUF = (TC + TP) * 64;
+    // layout: [buf][ W tile (TC rows) | X tile (TP rows) ], ROWB-byte rows; 128-byte rows: chunk XOR (row >> 1) & 7 puts the 16 rows
+    // of a ds_read_b128 lane group on 16 distinct 16-byte slots of the 256-byte bank window
+    constexpr int BUF = (TC + TP) * ROWB;
+    auto loff = [](int row, int chunk) { return KWID == 1 ? lds_off(row, chunk) : row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); };
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform: the epilogue builds buffer descriptors from it)
@@ -1588,13 +1597,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const int co0 = coTile * TC;
 
     // ---- per-thread staging coordinates (fixed over the K loop) --------------
-    const int chunk = tid & 3;
-    const int srow = tid >> 2;  // 0..63
+    const int chunk = tid % CPR;
+    const int srow = tid / CPR;  // 0..RPP-1
     int xt[XR], xh[XR], xw[XR];
     bool xvalid[XR];
 #pragma unroll
     for (int i = 0; i < XR; ++i) {
-        long p = p0 + srow + 64 * i;
+        long p = p0 + srow + RPP * i;
         xvalid[i] = p < a.P;
         if (!xvalid[i]) p = 0;
         int w_ = (int)(p % a.W);
@@ -1652,7 +1661,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         const unsigned kofs = (unsigned)(tap * a.CinTot + segOff + coff) * ESZ;
 #pragma unroll
         for (int j = 0; j < WR; ++j) {
-            const int n = co0 + srow + 64 * j;
+            const int n = co0 + srow + RPP * j;
             wreg[set][j] = buf_load16(wrs, n < a.Cout ? (unsigned)(n * taps * a.CinTot) * ESZ + kofs : FLAIR_OOB);
         }
     };
@@ -1682,10 +1691,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         char* base = smem + buf * BUF;
 #pragma unroll
         for (int j = 0; j < WR; ++j)
-            *reinterpret_cast<uint4*>(base + lds_off(srow + 64 * j, chunk)) = wreg[set][j];
+            *reinterpret_cast<uint4*>(base + loff(srow + RPP * j, chunk)) = wreg[set][j];
 #pragma unroll
         for (int i = 0; i < XR; ++i)
-            *reinterpret_cast<uint4*>(base + TC * 64 + lds_off(srow + 64 * i, chunk)) = xreg[set][i];
+            *reinterpret_cast<uint4*>(base + TC * ROWB + loff(srow + RPP * i, chunk)) = xreg[set][i];
     };
 
     f32x16 acc[FC][FP];
@@ -1720,24 +1729,27 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                 advance();
             }
             const char* wb = smem + cur * BUF;
-            const char* xb = wb + TC * 64;
-            uint4 af[FC][2], bfr[FP][2];
+            const char* xb = wb + TC * ROWB;
 #pragma unroll
-            for (int i = 0; i < FC; ++i) {
-                const int row = wc * (TC / WC) + i * 32 + lr;
-                af[i][0] = *reinterpret_cast<const uint4*>(wb + lds_off(row, Mma<E>::chunk(0, lh)));
-                af[i][1] = *reinterpret_cast<const uint4*>(wb + lds_off(row, Mma<E>::chunk(1, lh)));
+            for (int sp = 0; sp < KWID; ++sp) {            // 32 channels (two k16 MFMA steps for bf16) per pass
+                uint4 af[FC][2], bfr[FP][2];
+#pragma unroll
+                for (int i = 0; i < FC; ++i) {
+                    const int row = wc * (TC / WC) + i * 32 + lr;
+                    af[i][0] = *reinterpret_cast<const uint4*>(wb + loff(row, 4 * sp + Mma<E>::chunk(0, lh)));
+                    af[i][1] = *reinterpret_cast<const uint4*>(wb + loff(row, 4 * sp + Mma<E>::chunk(1, lh)));
+                }
+#pragma unroll
+                for (int j = 0; j < FP; ++j) {
+                    const int row = wp * (TP / WP) + j * 32 + lr;
+                    bfr[j][0] = *reinterpret_cast<const uint4*>(xb + loff(row, 4 * sp + Mma<E>::chunk(0, lh)));
+                    bfr[j][1] = *reinterpret_cast<const uint4*>(xb + loff(row, 4 * sp + Mma<E>::chunk(1, lh)));
+                }
+#pragma unroll
+                for (int i = 0; i < FC; ++i)
+#pragma unroll
+                    for (int j = 0; j < FP; ++j) Mma<E>::run(af[i], bfr[j], acc[i][j]);
             }
-#pragma unroll
-            for (int j = 0; j < FP; ++j) {
-                const int row = wp * (TP / WP) + j * 32 + lr;
-                bfr[j][0] = *reinterpret_cast<const uint4*>(xb + lds_off(row, Mma<E>::chunk(0, lh)));
-                bfr[j][1] = *reinterpret_cast<const uint4*>(xb + lds_off(row, Mma<E>::chunk(1, lh)));
-            }
-#pragma unroll
-            for (int i = 0; i < FC; ++i)
-#pragma unroll
-                for (int j = 0; j < FP; ++j) Mma<E>::run(af[i], bfr[j], acc[i][j]);
             if (k + 1 < nk) write_lds(cur ^ 1, (u + 1) % PD);
             __syncthreads();
         }
@@ -1827,14 +1839,14 @@ __global__ void conv_splitk_reduce_kernel(ConvArgs a) {
     }
 }
 
-template <typename E, int TC, int TP, int WC, int WP, int PD>
+template <typename E, int TC, int TP, int WC, int WP, int PD, int KWID>
 int launch_pd(const ConvArgs& a0, hipStream_t s) {
     ConvArgs a = a0;
     a.nPixTiles = cdiv(a.P, TP);
     a.nCoTiles = cdiv(a.Cout, TC);
     const int grid = a.nPixTiles * a.nCoTiles;
-    const size_t lds = 2 * (TC + TP) * 64;
-    hipLaunchKernelGGL((conv_igemm_kernel<E, TC, TP, WC, WP, PD>), dim3(grid, a.splitK), dim3(256), lds, s, a);
+    const size_t lds = 2 * (TC + TP) * 64 * KWID;
+    hipLaunchKernelGGL((conv_igemm_kernel<E, TC, TP, WC, WP, PD, KWID>), dim3(grid, a.splitK), dim3(256), lds, s, a);
     FLAIR_LAUNCH_CHECK();
     if (a.splitK > 1) {
         long g = (a.P * (a.Cout / 4) + 255) / 256;
@@ -1845,11 +1857,19 @@ int launch_pd(const ConvArgs& a0, hipStream_t s) {
     return FLAIR_OK;
 }
 
-// FLAIR_IGEMM_PD = 1 selects the one-step-ahead form of rounds 1-2 (A/B switch), default 4 steps in flight
+// FLAIR_IGEMM_PD = 1 selects the one-step-ahead form of rounds 1-2 (A/B switch), default 4 steps in flight;
+// FLAIR_IGEMM_WIDE = 0 keeps 32-channel K steps everywhere (default: 64-channel steps, two in flight, for bf16 convolutions whose
+// input segments are all multiples of 64 channels -- the same bytes in flight as four 32-channel steps)
 template <typename E, int TC, int TP, int WC, int WP>
 int launch(const ConvArgs& a, hipStream_t s) {
     static const int pd = getenv("FLAIR_IGEMM_PD") ? atoi(getenv("FLAIR_IGEMM_PD")) : 4;
-    return pd <= 1 ? launch_pd<E, TC, TP, WC, WP, 1>(a, s) : launch_pd<E, TC, TP, WC, WP, 4>(a, s);
+    static const int wide = getenv("FLAIR_IGEMM_WIDE") ? atoi(getenv("FLAIR_IGEMM_WIDE")) : 1;
+    if constexpr (sizeof(E) == 2) {
+        bool ok = wide && pd > 1;
+        for (int i = 0; i < a.nseg; ++i) ok = ok && a.segC[i] % 64 == 0;
+        if (ok) return launch_pd<E, TC, TP, WC, WP, 2, 2>(a, s);
+    }
+    return pd <= 1 ? launch_pd<E, TC, TP, WC, WP, 1, 1>(a, s) : launch_pd<E, TC, TP, WC, WP, 4, 1>(a, s);
 }
 
 // Split-K factor for the im2col path: deep-K convolutions on few pixels (the 16x16 .. 4x4
