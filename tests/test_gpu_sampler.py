@@ -117,6 +117,9 @@ def test_jpeg_roundtrip_vs_oracle(dev, qf):
     # flip one level in one 8x8 block (rare).  Bit-level agreement elsewhere: <=1e-4; allow
     # <=0.5% of pixels to sit in a flipped block.
     frac_bad = (diff > 1e-4).float().mean().item()
+    from tests.util import parity_log
+    parity_log(f"JPEG encode -> decode qf={qf} (2 x 3 x 64 x 64) vs oracle: {100 * frac_bad:.3f} % of pixels differ by more than 1e-4 "
+               f"(a flipped level in their 8x8 block; bound 0.5 %), max |diff| {diff.max().item():.2e}")
     assert frac_bad <= 5e-3, (frac_bad, diff.max().item())
 
 
@@ -143,11 +146,16 @@ def test_jpeg_quantised_levels_bit_exact(dev, qf):
     pre_c = odeg._unblocks(odeg._lin2d(odeg._blocks(ycc[:, 1:, ::2, ::2]).reshape(-1, 8, 8) - 128, D).view(-1, 2, 8, 8) / q2, 2, 2, 32)
     assert torch.equal(pre_l.round(), ref_luma) and torch.equal(pre_c.round(), ref_chroma)
     got_luma, got_chroma = (t.cpu() for t in jpeg_encode(x.to(dev), qf))
-    for got, ref, pre in ((got_luma, ref_luma, pre_l), (got_chroma, ref_chroma, pre_c)):
+    from tests.util import parity_log
+    report = []
+    for name, got, ref, pre in (("luma", got_luma, ref_luma, pre_l), ("chroma", got_chroma, ref_chroma, pre_c)):
         assert got.shape == ref.shape and torch.equal(got, got.round())
         near_tie = ((pre - pre.floor()) - 0.5).abs() < 2e-3
         assert torch.equal(got[~near_tie], ref[~near_tie])
         assert (got - ref).abs().max().item() <= 1.0 and near_tie.float().mean().item() < 0.01
+        report.append(f"{name}: {int(near_tie.sum())} of {near_tie.numel()} coefficients within 2e-3 of a .5 boundary "
+                      f"({100 * near_tie.float().mean().item():.3f} %, exempt), {int((got != ref).sum())} of them one level off")
+    parity_log(f"JPEG quantised levels qf={qf} (2 x 3 x 64 x 64): bit-exact outside the exempt set; " + "; ".join(report))
 
 
 @pytest.mark.parametrize("f", [8, 16])
