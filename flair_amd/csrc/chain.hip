@@ -25,6 +25,8 @@
 //   * stage B reads its B operands straight from that LDS tile.
 // MFMA operand roles, the 80-byte LDS pitch (conflict-free ds_read_b128) and the tap loop are those of
 // conv3x3_halo_kernel (conv.hip); a work item is 32 pixels x 64 output channels on one wavefront.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -154,18 +156,18 @@ __global__ __launch_bounds__(512, 2) void conv_chain_kernel(ChainArgs a) {
         iq[i] = (unsigned)(ch * BKE + (id & 3) * VEC) * ESZ;     // byte offset inside the pixel's channels
         idst[i] = id < IN_PIECES ? (ch * NP + pix) * PITCH + (id & 3) * 16 : -1;
     }
-    uint4 hreg[HI], wreg[WI];
+    uint4 hreg[2][HI], wreg[2][WI];        // two register sets: stage A keeps the operands of two K chunks in flight
 
     // K walk of stage A over (segment, chunk)
     int seg = 0, cb = 0, segOff = 0;
-    auto issue_in = [&]() {
+    auto issue_in = [&](int set) {
         const unsigned ld = (unsigned)a.segLd[seg] * ESZ;
         const char* frame = reinterpret_cast<const char*>(a.x[seg]) + (size_t)frameOff * ld;
         const __amdgpu_buffer_rsrc_t xr = make_rsrc(frame, a.segBytes[seg]);
         const unsigned cofs = (unsigned)(cb * BKE) * ESZ;
 #pragma unroll
         for (int i = 0; i < HI; ++i)
-            hreg[i] = buf_load16(xr, ipix[i] >= 0 ? (unsigned)ipix[i] * ld + cofs + iq[i] : FLAIR_OOB);
+            hreg[set][i] = buf_load16(xr, ipix[i] >= 0 ? (unsigned)ipix[i] * ld + cofs + iq[i] : FLAIR_OOB);
     };
     auto advance_in = [&]() {
         ++cb;
@@ -176,28 +178,28 @@ __global__ __launch_bounds__(512, 2) void conv_chain_kernel(ChainArgs a) {
         }
     };
     // weights of `rows` output channels starting at co0, K chunk at element offset kofs of a [Cout][9][cin] pack
-    auto issue_w = [&](const __amdgpu_buffer_rsrc_t& wrs, int co0, int coutTot, int cin, int kofs) {
+    auto issue_w = [&](int set, const __amdgpu_buffer_rsrc_t& wrs, int co0, int coutTot, int cin, int kofs) {
 #pragma unroll
         for (int i = 0; i < WI; ++i) {
             const int id = i * NT + tid;
             const int row = id >> 2;
             const int co = row / 9, tap9 = row % 9;
             const bool ok = id < W_PIECES && co0 + co < coutTot;
-            wreg[i] = buf_load16(wrs, ok ? (unsigned)(((co0 + co) * 9 + tap9) * cin + kofs + (id & 3) * VEC) * ESZ
-                                         : FLAIR_OOB);
+            wreg[set][i] = buf_load16(wrs, ok ? (unsigned)(((co0 + co) * 9 + tap9) * cin + kofs + (id & 3) * VEC) * ESZ
+                                              : FLAIR_OOB);
         }
     };
-    auto write_w = [&]() {
+    auto write_w = [&](int set) {
 #pragma unroll
         for (int i = 0; i < WI; ++i) {
             const int id = i * NT + tid;
-            if (id < W_PIECES) *reinterpret_cast<uint4*>(sw + (id >> 2) * PITCH + (id & 3) * 16) = wreg[i];
+            if (id < W_PIECES) *reinterpret_cast<uint4*>(sw + (id >> 2) * PITCH + (id & 3) * 16) = wreg[set][i];
         }
     };
-    auto write_in = [&](char* dst) {
+    auto write_in = [&](char* dst, int set) {
 #pragma unroll
         for (int i = 0; i < HI; ++i)
-            if (idst[i] >= 0) *reinterpret_cast<uint4*>(dst + idst[i]) = hreg[i];
+            if (idst[i] >= 0) *reinterpret_cast<uint4*>(dst + idst[i]) = hreg[set][i];
     };
 
     // 9 taps x one K chunk for one work item (32 pixels x 64 couts): B fragments from `pb` (this lane's
@@ -234,9 +236,21 @@ __global__ __launch_bounds__(512, 2) void conv_chain_kernel(ChainArgs a) {
         // ================================ stage A ================================
         const __amdgpu_buffer_rsrc_t wArs = make_rsrc(a.wA, a.wABytes);
         const int nkA = a.CinA / BKE;
-        issue_in();
-        issue_w(wArs, 0, C, a.CinA, segOff + cb * BKE);
-        advance_in();
+        // K chunk k lives in register set k & 1: requested two chunks ahead of its multiplication, written to LDS one chunk ahead.
+        // With one set (round 2) a chunk was in flight only while the previous one was multiplied -- 0.5-1 us, less than one round
+        // trip to the L2 -- and every chunk ended waiting for its successor (stamps: stage-A K loop 12.4 k cycles against an MFMA
+        // floor of 6.9 k).  "Chunk nkA" is the first weight chunk of stage B.
+        auto issue_step = [&](int k, int set) {
+            if (k < nkA) {
+                issue_in(set);
+                issue_w(set, wArs, 0, C, a.CinA, segOff + cb * BKE);
+                advance_in();
+            } else if (k == nkA) {
+                issue_w(set, wBrs, 0, a.CoutB, C, 0);
+            }
+        };
+        issue_step(0, 0);
+        issue_step(1, 1);
         // this lane's pixel of the intermediate region for each of its items; the accumulators start at the
         // bias (lane layout of the 32x32 MFMA result: register r <-> cout 8*(r/4) + 4*lh + r%4 of the fragment)
         f32x16 accA[MAXIA][2];
@@ -259,26 +273,25 @@ __global__ __launch_bounds__(512, 2) void conv_chain_kernel(ChainArgs a) {
                     accA[ii][i][4 * gq + 2] = bq.z; accA[ii][i][4 * gq + 3] = bq.w;
                 }
         }
-        write_in(sin);
-        write_w();
+        write_in(sin, 0);
+        write_w(0);
         __syncthreads();
         STAMP(1);
-        for (int k = 0; k < nkA; ++k) {
-            if (k + 1 < nkA) {
-                issue_in();
-                issue_w(wArs, 0, C, a.CinA, segOff + cb * BKE);
-                advance_in();
-            } else {
-                issue_w(wBrs, 0, a.CoutB, C, 0);                  // first weights of stage B
-            }
+        auto step = [&](int k, auto setTag) {
+            constexpr int SET = decltype(setTag)::value;
+            issue_step(k + 2, SET);                                // set SET went to LDS before this chunk's barrier: free again
 #pragma unroll
             for (int ii = 0; ii < MAXIA; ++ii)
                 if (wave + ii * NW < NITA)
                     compute(sin + pbOff[ii], WA, sw + wbOff[ii], sw + wbOff[ii] + 32 * 9 * PITCH, accA[ii]);
             __syncthreads();                                       // everyone is done with the staged chunk
-            if (k + 1 < nkA) write_in(sin);
-            write_w();
+            if (k + 1 < nkA) write_in(sin, SET ^ 1);
+            write_w(SET ^ 1);                                      // chunk k + 1 (k + 1 == nkA: stage B's first weights)
             if (k + 1 < nkA) __syncthreads();
+        };
+        for (int k = 0; k < nkA; k += 2) {
+            step(k, std::integral_constant<int, 0>{});
+            if (k + 1 < nkA) step(k + 1, std::integral_constant<int, 1>{});
         }
         STAMP(2);
         // ---- intermediate -> LDS (bias, activation, zero outside the image, element type rounding)
@@ -314,10 +327,10 @@ __global__ __launch_bounds__(512, 2) void conv_chain_kernel(ChainArgs a) {
         __syncthreads();
     } else {
         // the intermediate IS the input: all channel chunks of the (TH+2) x (TW+2) halo, staged once
-        issue_in();
-        issue_w(wBrs, 0, a.CoutB, C, 0);
-        write_in(smid);
-        write_w();
+        issue_in(0);
+        issue_w(0, wBrs, 0, a.CoutB, C, 0);
+        write_in(smid, 0);
+        write_w(0);
         __syncthreads();
     }
     STAMP(3);
@@ -351,14 +364,14 @@ __global__ __launch_bounds__(512, 2) void conv_chain_kernel(ChainArgs a) {
             // prefetch the next (batch, chunk) weights
             const bool lastChunk = ch + 1 == NCH;
             const bool more = !lastChunk || batch + 1 < nBatch;
-            if (more) issue_w(wBrs, lastChunk ? (batch + 1) * WROWS : batch * WROWS, a.CoutB, C, lastChunk ? 0 : (ch + 1) * BKE);
+            if (more) issue_w(0, wBrs, lastChunk ? (batch + 1) * WROWS : batch * WROWS, a.CoutB, C, lastChunk ? 0 : (ch + 1) * BKE);
 #pragma unroll
             for (int ii = 0; ii < MAXIB; ++ii)
                 if (wave + ii * NW < NITB)
                     compute(smid + ch * NPM * PITCH + pbB[ii], WM, sw + wbB[ii], sw + wbB[ii] + 32 * 9 * PITCH, acc[ii]);
             __syncthreads();                                       // sw is free
             if (!lastChunk) {
-                write_w();
+                write_w(0);
                 __syncthreads();
             }
         }
@@ -445,7 +458,7 @@ __global__ __launch_bounds__(512, 2) void conv_chain_kernel(ChainArgs a) {
         }
         if (batch == 0) STAMP(5);
         if (batch + 1 < nBatch) {
-            write_w();
+            write_w(0);
             __syncthreads();
         }
     }
