@@ -23,5 +23,5 @@ def key(s): return json.dumps(s['shape'],sort_keys=True)
 sa={key(s):s for s in a['roofline']['by_shape']}; sb={key(s):s for s in b['roofline']['by_shape']}
 for k in sa:
     if k in sb:
-        print(k, sa[k]['launches'], round(sa[k]['us_per_launch_isolated_replay'],1), round(sb[k]['us_per_launch_isolated_replay'],1))
+        print(k, sa[k]['launches'], round(sa[k]['us_per_launch'],1), round(sb[k]['us_per_launch'],1))
 PY
