@@ -483,7 +483,10 @@ static int gn_blocks_per_stat(const flair_gn_params* p) {
     const int rows = 256 / cv > 0 ? 256 / cv : 1;
     const long pix = (long)p->frames_per_stat * p->H * p->W;
     long bps = (pix + (long)rows * 16 - 1) / ((long)rows * 16);
-    if (bps > 1024) bps = 1024;
+    // cap of statistics workgroups per statistic (FLAIR_GN_PARTIAL_BLOCKS; 1024 until round 3: 512 streams as fast with half the
+    // partials for gn_finalize: whole norm 75.6 -> 73.3 us on 16x256^2x64, 44.8 -> 41.8 us on 16x128^2x128; 256: equal, 128: slower)
+    static const int cap = getenv("FLAIR_GN_PARTIAL_BLOCKS") ? atoi(getenv("FLAIR_GN_PARTIAL_BLOCKS")) : 512;
+    if (bps > cap) bps = cap;
     if (bps < 1) bps = 1;
     return (int)bps;
 }
