@@ -183,6 +183,14 @@ def deform_conv2d(x, offset, weight, bias=None, stride=(1, 1), padding=(0, 0),
     offset: (n, 2*G*kh*kw, ho, wo) with channel 2*(g*kh*kw+k) = dy, +1 = dx;
     mask:   (n, G*kh*kw, ho, wo); bilinear sampling, zero outside the image.
     out[n,co] = bias[co] + sum_{ci,k} W[co,ci,k] * mask[g(ci),k] * sample(x[ci], p0+pk+d).
+
+    Pinned to source the reference itself holds: the same operator exists there as
+    guided_diffusion/dcn/src/deform_conv_cuda_kernel.cu:468-497 (dmcn_im2col_bilinear), :571-633
+    (modulated_deformable_im2col_gpu_kernel: offset channel 2*(g*kh*kw+k) = row displacement, +1 = column
+    displacement, mask channel g*kh*kw+k, the `h_im > -1 && h_im < height` window) and deform_conv_cuda.cpp:540-560
+    (im2col + addmm + bias).  oracle/dcn_ref.py restates those lines literally in numpy (loops, no grid_sample) and
+    tests/test_dcn_ref_cpu.py holds this function to it (f64: 1e-11, incl. positions in (-1, 0), >= H-1, exactly
+    integer, exactly -1 / H and far outside).
     """
     def _pair(v):
         return (v, v) if isinstance(v, int) else tuple(v)

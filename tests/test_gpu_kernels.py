@@ -433,6 +433,42 @@ def test_dcn_activated_raw(dev, dtype, c, hw):
     assert_close(from_clip(y), ref, dtype, f"dcn activated c={c}", scale=2.0)
 
 
+@pytest.mark.parametrize("c,hw", [(64, (16, 32)), (128, (8, 16)), (64, (11, 13))])
+def test_dcn_vs_reference_source(dev, c, hw):
+    """flair_dcn_align (f32, finished residues / masks) against oracle/dcn_ref.py, the literal restatement of the
+    reference's own DCNv2 source (dcn/src/deform_conv_cuda_kernel.cu:468-497,571-633), on offsets that put sampling
+    positions in (-1, 0), at and beyond H - 1 / W - 1, exactly on integers, exactly at -1 / H and far outside."""
+    from oracle import dcn_ref
+    ops = _ops()
+    dtype = torch.float32
+    H, W, G = hw[0], hw[1], 16
+    g = torch.Generator().manual_seed(77 + c)
+    x = torch.randn(1, 2 * c, H, W, generator=g)
+    w = torch.randn(c, 2 * c, 3, 3, generator=g) / math.sqrt(18 * c)
+    b = torch.randn(c, generator=g) * 0.1
+    offset = torch.randn(1, 2 * G * 9, H, W, generator=g) * 3
+    mask = torch.rand(1, G * 9, H, W, generator=g)
+    off = offset.view(1, G, 9, 2, H, W)
+    hh = torch.arange(H, dtype=torch.float32).view(1, H, 1)
+    ww = torch.arange(W, dtype=torch.float32).view(1, 1, W)
+    targets = [(-0.5, 0.25), (-1.0, 2.0), (-0.999, -0.001), (H - 1.0, W - 1.0), (H - 0.5, W - 0.25),
+               (float(H), 1.0), (2.0, 3.0), (H - 1.25, -1.0), (-3.0, 1.5)]
+    for k in range(9):
+        i, j = divmod(k, 3)
+        off[:, k, k, 0] = (targets[k][0] - (hh - 1 + i)).expand(1, H, W)
+        off[:, k, k, 1] = (targets[k][1] - (ww - 1 + j)).expand(1, H, W)
+    off[:, G - 1] = torch.round(off[:, G - 1])
+    ref = torch.from_numpy(dcn_ref.modulated_deform_conv_forward(x.numpy(), w.numpy(), b.numpy(), offset.numpy(),
+                                                                 mask.numpy(), deformable_group=G))
+    act = torch.cat([offset, mask], dim=1)                      # the reference's channel order: (o1 | o2 | mask)
+    wp = ops.pack_conv_weight(w, [(2 * c, 2 * c)], dtype).to(dev)
+    y = ops.dcn_align(to_clip(x[:, :c], dtype, dev), to_clip(x[:, c:], dtype, dev),
+                      to_clip(act[:, ops.dcn_raw_permutation(G)], dtype, dev), None, None, wp, b.to(dev), c,
+                      raw_activated=True)
+    torch.cuda.synchronize()
+    assert_close(from_clip(y), ref, dtype, f"dcn vs reference source c={c}", scale=2.0)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("path", ["halo", "igemm", "chain"])
 def test_dcn_offset_activation_epilogue(dev, dtype, path):
