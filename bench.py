@@ -213,42 +213,79 @@ def spawn_ranks(n, wall_limit_s=None):
         f.seek(max(0, size - nbytes))
         return f.read().decode("utf-8", "replace")
 
-    def stop_all():
+    def stop_all(sig=None):
+        """Every child leads its own session (start_new_session above), so a kill of this process's group misses them:
+        signal each child's process group explicitly, then reap."""
+        import signal as _sg
         for q in procs:
             if q.poll() is None:
-                q.terminate()
+                try:
+                    os.killpg(q.pid, sig or _sg.SIGTERM)
+                except (ProcessLookupError, PermissionError):
+                    pass
         t_end = time.time() + 10
         for q in procs:
             try:
                 q.wait(timeout=max(0.1, t_end - time.time()))
             except subprocess.TimeoutExpired:
-                q.kill()
+                try:
+                    os.killpg(q.pid, _sg.SIGKILL)
+                except (ProcessLookupError, PermissionError):
+                    pass
+                q.wait()
 
+    def cleanup():
+        import shutil
+        for out, err in logs:
+            out.close()
+            err.close()
+        shutil.rmtree(tmp, ignore_errors=True)
+
+    class _Stopped(Exception):
+        pass
+
+    def on_signal(signum, _frame):
+        raise _Stopped(signum)
+
+    import signal
+    old_handlers = {sg: signal.signal(sg, on_signal) for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP)}
     t0 = time.time()
     failed = None
-    while True:
-        codes = [q.poll() for q in procs]
-        bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
-        if bad:
-            failed = (bad[0], f"rank {bad[0]} exited with status {codes[bad[0]]}")
-            break
-        if all(c == 0 for c in codes):
-            break
-        if time.time() - t0 > wall_limit_s:
-            failed = (0, f"wall limit of {wall_limit_s:.0f} s passed (ranks still running: "
-                         f"{[r for r, c in enumerate(codes) if c is None]})")
-            break
-        time.sleep(0.2)
-    if failed is not None:
+    rc = 1
+    try:
+        while True:
+            codes = [q.poll() for q in procs]
+            bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                failed = (bad[0], f"rank {bad[0]} exited with status {codes[bad[0]]}")
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.time() - t0 > wall_limit_s:
+                failed = (0, f"wall limit of {wall_limit_s:.0f} s passed (ranks still running: "
+                             f"{[r for r, c in enumerate(codes) if c is None]})")
+                break
+            time.sleep(0.2)
+        if failed is not None:
+            r, why = failed
+            sys.stderr.write(f"bench.py --gpus {n}: {why}; stderr tail of rank {r}:\n{tail(logs[r][1])}\n")
+            sys.stderr.flush()
+        else:
+            sys.stdout.write(tail(logs[0][0], 1 << 20))
+            sys.stdout.flush()
+            sys.stderr.write(tail(logs[0][1]))
+            rc = 0
+    except _Stopped as e:
+        sys.stderr.write(f"bench.py --gpus {n}: signal {e.args[0]} received, stopping the rank processes\n")
+        rc = 128 + int(e.args[0])
+    finally:
+        # whatever ended the loop (a failing rank, the wall limit, a signal from the driver, an exception): no rank process
+        # outlives this one, the per-rank log files are closed and the temporary directory removed
+        for sg, h in old_handlers.items():
+            signal.signal(sg, h)
         stop_all()
-        r, why = failed
-        sys.stderr.write(f"bench.py --gpus {n}: {why}; stderr tail of rank {r}:\n{tail(logs[r][1])}\n")
-        sys.stderr.flush()
-        return 1
-    sys.stdout.write(tail(logs[0][0], 1 << 20))
-    sys.stdout.flush()
-    sys.stderr.write(tail(logs[0][1]))
-    return 0
+        cleanup()
+    return rc
 
 
 def main():

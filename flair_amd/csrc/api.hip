@@ -14,7 +14,7 @@ void flair_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* flair_last_error(void) { return g_err; }
-extern "C" int flair_abi_version(void) { return 3; }
+extern "C" int flair_abi_version(void) { return 5; }
 
 // ---- multi-GPU start-up: the one collective of the path (replaces dist_util.py:40-79's pickled-chunk
 // load_state_dict + per-parameter sync_params).  RCCL is bound at run time (dlopen of the librccl the process already has:

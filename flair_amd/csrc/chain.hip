@@ -471,12 +471,10 @@ int launch_chain(const ChainArgs& a, hipStream_t s) {
     constexpr size_t lds = (size_t)(C / BKE) * (TH + 2) * (TW + 2) * 80 + (size_t)C * 9 * 80 +
                            (HASA ? (size_t)(TH + 4) * (TW + 4) * 80 : 0) + (size_t)(C + CHAIN_MAX_COUTB) * 4;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static bool attr = false;
-    if (!attr) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_chain_kernel<E, C, TH, TW, HASA>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static LdsAttrOnce attr;
+    {
+        const hipError_t e = flair_max_lds_once(attr, reinterpret_cast<const void*>(&conv_chain_kernel<E, C, TH, TW, HASA>));
         FLAIR_CHECK(e == hipSuccess, "flair_conv_chain: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr = true;
     }
     const int grid = a.T * cdiv(a.H, TH) * (a.W / TW);
     hipLaunchKernelGGL((conv_chain_kernel<E, C, TH, TW, HASA>), dim3(grid), dim3(512), lds, s, a);

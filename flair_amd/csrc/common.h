@@ -162,4 +162,29 @@ __device__ __forceinline__ void prefetch_kernargs() {
                      : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6), "=&s"(t7) : "s"(ka) : "memory");
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) and the CU count are PER DEVICE in HIP: cache them per (kernel instantiation,
+// device), not per process, so that a process which later runs on a second GPU configures that device too.  (Races between
+// host threads are benign: the calls are idempotent.)
+struct LdsAttrOnce {
+    unsigned long long done = 0;      // bit d: device d configured (devices >= 64: configured on every call)
+};
+static inline hipError_t flair_max_lds_once(LdsAttrOnce& st, const void* fn, int bytes = 160 * 1024) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+    if (dev >= 0 && dev < 64 && ((st.done >> dev) & 1ull)) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess && dev >= 0 && dev < 64) st.done |= 1ull << dev;
+    return e;
+}
+static inline int flair_cu_count() {
+    static int cus[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cus[dev]) {
+        hipDeviceProp_t prop;
+        cus[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return cus[dev];
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

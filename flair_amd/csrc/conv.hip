@@ -946,12 +946,10 @@ int launch_halo_ks(const ConvArgs& a0, hipStream_t s) {
     a.nCoTiles = cdiv(a.Cout, 64);
     const int grid = a.T * cdiv(a.H, TH) * (a.W / 32) * a.nCoTiles;
     const size_t lds = 2 * ((size_t)(TH + 2) * 34 * 80 + 64 * 9 * 80);
-    static bool attr = false;
-    if (!attr) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_ks_kernel<E, TH, RPW, CF>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static LdsAttrOnce attr;
+    {
+        const hipError_t e = flair_max_lds_once(attr, reinterpret_cast<const void*>(&conv3x3_halo_ks_kernel<E, TH, RPW, CF>));
         FLAIR_CHECK(e == hipSuccess, "flair_conv_nhwc: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr = true;
     }
     hipLaunchKernelGGL((conv3x3_halo_ks_kernel<E, TH, RPW, CF>), dim3(grid), dim3(256 * TH / RPW / CF), lds, s, a);
     FLAIR_LAUNCH_CHECK();
@@ -1533,25 +1531,17 @@ int launch_dma(const ConvArgs& a0, hipStream_t s) {
     ConvArgs a = a0;
     a.nCoTiles = cdiv(a.Cout, 64);
     const int nTiles = a.T * (a.H / TH) * (a.W / 32) * a.nCoTiles;
-    static int nCu = 0;
-    if (!nCu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) nCu = prop.multiProcessorCount;
-        if (nCu <= 0) nCu = 256;
-    }
+    const int nCu = flair_cu_count();                                  // of the CURRENT device
     int grid = nTiles < nCu ? (nTiles + 7) / 8 * 8 : nCu / 8 * 8;      // a multiple of 8: every XCD gets the same number of slots
     if (grid < 8) grid = 8;
     const int tilesPerXcd = (nTiles + 7) / 8;
     constexpr int HALO_INSTR = ((TH + 2) * 34 + 15) / 16;
     const size_t lds = NSTAGE * (size_t)(HALO_INSTR + 36) * 1024 + NW * 1024 + 512;  // stages + idle DMA slots' scratch + two bias slots
     if (NSTAGE == 3) FLAIR_CHECK(nTiles <= grid, "flair_conv_nhwc: the three-stage form runs one tile per workgroup");
-    static bool attr = false;
-    if (!attr) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_dma_kernel<NW, RPW, NSTAGE>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static LdsAttrOnce attr;
+    {
+        const hipError_t e = flair_max_lds_once(attr, reinterpret_cast<const void*>(&conv3x3_dma_kernel<NW, RPW, NSTAGE>));
         FLAIR_CHECK(e == hipSuccess, "flair_conv_nhwc: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr = true;
     }
     hipLaunchKernelGGL((conv3x3_dma_kernel<NW, RPW, NSTAGE>), dim3(grid), dim3(64 * NW), lds, s, a, nTiles, tilesPerXcd);
     FLAIR_LAUNCH_CHECK();

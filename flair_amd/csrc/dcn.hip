@@ -507,12 +507,10 @@ static int launch_dcn_v(const DcnArgs& a0, hipStream_t stream) {
     constexpr int NT = 32 * NPF * TPP, TP = 32 * NPF, TC = 32 * NCF;
     const int rawPitch = 3 * a.G * (int)sizeof(E) + 16;
     const size_t lds = (size_t)2 * TP * rawPitch + 2 * (TC + TP) * TPP * 16;
-    static bool attr = false;
-    if (!attr) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_kernel<E, NCF, NPF, TPP, ACTIVATED, ONEFRAME, PFD>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static LdsAttrOnce attr;
+    {
+        const hipError_t e = flair_max_lds_once(attr, reinterpret_cast<const void*>(&dcn_kernel<E, NCF, NPF, TPP, ACTIVATED, ONEFRAME, PFD>));
         FLAIR_CHECK(e == hipSuccess, "flair_dcn_align: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr = true;
     }
     hipLaunchKernelGGL((dcn_kernel<E, NCF, NPF, TPP, ACTIVATED, ONEFRAME, PFD>), dim3(cdiv(a.P, TP)), dim3(NT), lds, stream, a);
     FLAIR_LAUNCH_CHECK();

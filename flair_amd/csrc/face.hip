@@ -78,16 +78,16 @@ __global__ __launch_bounds__(256) void warp_affine_cubic_kernel(const T* src, in
         if (outside) {
             sum = cv;
         } else if (inner) {
+            // imgwarp.cpp remapBicubic: the four taps of a row are summed first (left to right), then the row sum is
+            // added to the running sum -- sum = row0; sum += row1; ... -- which rounds differently from 16 sequential adds
             sum = 0;
-            bool first = true;
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < 4; ++r) {
+                T row = fetch(P, (long)(sy + r) * Ws + sx) * (T)(cy[r] * cx[0]);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const T term = fetch(P, (long)(sy + r) * Ws + sx + c) * (T)(cy[r] * cx[c]);
-                    sum = first ? term : sum + term;
-                    first = false;
-                }
+                for (int c = 1; c < 4; ++c) row = row + fetch(P, (long)(sy + r) * Ws + sx + c) * (T)(cy[r] * cx[c]);
+                sum = r == 0 ? row : sum + row;
+            }
         } else {
             sum = cv;                                            // cv * ONE, then (S - cv) * w for the taps inside the image
 #pragma unroll

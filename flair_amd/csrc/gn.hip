@@ -485,7 +485,11 @@ static int gn_blocks_per_stat(const flair_gn_params* p) {
     long bps = (pix + (long)rows * 16 - 1) / ((long)rows * 16);
     // cap of statistics workgroups per statistic (FLAIR_GN_PARTIAL_BLOCKS; 1024 until round 3: 512 streams as fast with half the
     // partials for gn_finalize: whole norm 75.6 -> 73.3 us on 16x256^2x64, 44.8 -> 41.8 us on 16x128^2x128; 256: equal, 128: slower)
-    static const int cap = getenv("FLAIR_GN_PARTIAL_BLOCKS") ? atoi(getenv("FLAIR_GN_PARTIAL_BLOCKS")) : 512;
+    static const int cap = [] {
+        const char* e = getenv("FLAIR_GN_PARTIAL_BLOCKS");
+        const int v = e ? atoi(e) : 512;
+        return v >= 1 && v <= 4096 ? v : 512;          // an unparsable or out-of-range value keeps the default
+    }();
     if (bps > cap) bps = cap;
     if (bps < 1) bps = 1;
     return (int)bps;
@@ -544,14 +548,11 @@ extern "C" int flair_groupnorm_nhwc(const flair_gn_params* p, const void* x0, co
             a.act = p->act; a.resample = 0;
             a.y = y; a.yLd = p->y_ld; a.raw = nullptr; a.rawLd = 0; a.blocksPerFrame = 0;
             a.filmVec = film && p->film_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(film) & 15) == 0;
-            static bool attr = false;
-            if (!attr) {
-                const hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_group_kernel<bf16_t>),
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-                const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_group_kernel<float>),
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            static LdsAttrOnce attr0, attr1;
+            {
+                const hipError_t e0 = flair_max_lds_once(attr0, reinterpret_cast<const void*>(&gn_group_kernel<bf16_t>), 128 * 1024);
+                const hipError_t e1 = flair_max_lds_once(attr1, reinterpret_cast<const void*>(&gn_group_kernel<float>), 128 * 1024);
                 FLAIR_CHECK(e0 == hipSuccess && e1 == hipSuccess, "flair_groupnorm_nhwc: hipFuncSetAttribute failed");
-                attr = true;
             }
             const int grid = nstat * p->groups;
             if (p->dtype == FLAIR_BF16)

@@ -284,14 +284,11 @@ extern "C" int flair_attention_wide(const flair_attn_params* p, const void* qkv,
     WideAttn a;
     a.qkv = qkv; a.out = out; a.ld = p->ld; a.outLd = p->out_ld; a.L = p->L; a.heads = p->heads; a.d = p->head_dim;
     a.qOff = p->q_off; a.kOff = p->k_off; a.vOff = p->v_off; a.headStride = p->head_stride; a.scale = p->scale;
-    static bool attr = false;
-    if (!attr) {
-        const hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_wide_kernel<bf16_t>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_wide_kernel<float>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    static LdsAttrOnce attr0, attr1;
+    {
+        const hipError_t e0 = flair_max_lds_once(attr0, reinterpret_cast<const void*>(&attn_wide_kernel<bf16_t>), 128 * 1024);
+        const hipError_t e1 = flair_max_lds_once(attr1, reinterpret_cast<const void*>(&attn_wide_kernel<float>), 128 * 1024);
         FLAIR_CHECK(e0 == hipSuccess && e1 == hipSuccess, "flair_attention_wide: hipFuncSetAttribute failed");
-        attr = true;
     }
     const dim3 grid((p->L + 15) / 16, p->frames * p->heads);
     if (p->dtype == FLAIR_BF16)

@@ -52,6 +52,7 @@ class FaceRestoreHelper(object):
         self.face_parse = face_parse          # flair_amd.guided_diffusion.parsenet.ParseNet (needed by inverse_faces)
         self.detector = detector
         self._const = {}
+        self._minv_cache = {}
 
     # -- detection half (not built: RetinaFace weights are a network download, alignment is cv2 glue)
     def get_crop_face(self, *args, **kwargs):
@@ -69,10 +70,21 @@ class FaceRestoreHelper(object):
             self._const[dev] = c
         return c
 
-    @staticmethod
-    def _minv(mats, dev):
-        """The dst -> src matrices warpAffine derives from its argument (its inverse, in double): (N, 6) on the GPU."""
-        return torch.from_numpy(np.stack([invert_affine(m).reshape(6) for m in mats])).to(dev)
+    def _minv(self, mats, dev, twice=False):
+        """The dst -> src matrices warpAffine derives from its argument (its inverse, in double): (N, 6) on the GPU.
+        ``twice``: of the INVERSE matrices (inverse_faces warps with inverse_affine, which warpAffine inverts again).
+        Cached per matrix list by content: the sampler passes the same list to three calls in every denoising step, and an
+        upload from pageable host memory is a synchronous copy in the middle of the step."""
+        arr = np.stack([np.asarray(m, dtype=np.float64).reshape(2, 3) for m in mats])
+        key = (arr.tobytes(), str(dev), bool(twice))
+        hit = self._minv_cache.get(key)
+        if hit is None:
+            src = [invert_affine(m) for m in arr] if twice else list(arr)
+            hit = torch.from_numpy(np.stack([invert_affine(m).reshape(6) for m in src])).to(dev)
+            if len(self._minv_cache) >= 64:
+                self._minv_cache.clear()
+            self._minv_cache[key] = hit
+        return hit
 
     def get_crop_face_from_affine_matrices(self, bathed_imgs, affine_matrices):
         """(B, 3, H, W) in [-1, 1] -> (B, 3, face_h, face_w) in [-1, 1]: per frame
@@ -103,7 +115,7 @@ class FaceRestoreHelper(object):
                                                                           device=x.device))
         mask = ops.face_mask_blur(idx, B, h, w, lut, kern, repeats=2, edge=10, div=255.0)
         # warpAffine(., inverse_affine) inverts its argument again: dst -> src = inv(inv(M)), rounded as OpenCV rounds it
-        minv = self._minv(self.get_inverse_affine(affine_matrices), x.device)
+        minv = self._minv(affine_matrices, x.device, twice=True)
         inv_faces = ops.warp_affine_cubic(x, minv, (h, w), pre=True, post=True)
         inv_masks = ops.warp_affine_cubic(mask, minv, (h, w))
         return inv_faces, inv_masks

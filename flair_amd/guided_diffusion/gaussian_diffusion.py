@@ -262,6 +262,9 @@ class GaussianDiffusion:
                                      "(gaussian_diffusion.py:476-483)")
                 aux_face = face_restore_helper.get_crop_face_from_affine_matrices(x0, affine_matrices)
                 aux_xt = face_restore_helper.get_crop_face_from_affine_matrices(x, affine_matrices)
+                if aux_face is None or aux_xt is None:
+                    # (the reference hands None on to aux_model here, gaussian_diffusion.py:484-486, and fails inside it)
+                    raise ValueError("aligned=False: no face crop (affine_matrices is empty): one affine matrix per frame is needed")
                 aux_face = aux_model(aux_face, t, aux_xt)
                 inv_face, inv_mask = face_restore_helper.inverse_faces(aux_face, affine_matrices)
                 if tuple(inv_face.shape) != tuple(x0.shape):

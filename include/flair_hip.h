@@ -58,7 +58,10 @@ typedef enum {
 
 /* Last error message of the calling thread ("" if none). */
 const char* flair_last_error(void);
-/* ABI version of this header (bumped on incompatible change). */
+/* ABI version of this header: bumped whenever entry points are added or a struct changes
+ * (3: round 2; 4: + face crop / paste entries, flair_bcast_weights; 5: round 4 entries).
+ * The library may be used from several devices of one process: per-kernel launch attributes and
+ * CU counts are cached per device. */
 int flair_abi_version(void);
 
 /* ------------------------------------------------------------------ convolution
@@ -161,7 +164,9 @@ int flair_conv_chain(const flair_chain_params* p, const void* const* x, const vo
  * SiLU / (1+scale)*h+shift / Upsample / Downsample steps of unet_new.py:237-329, the
  * attention norms (:358,:408,:461) and the head (:1216-1222).
  *   gamma, beta : [C] f32;  film : [F][film_ld] f32 rows of (scale[C] | shift[C]) or NULL
- *   workspace   : flair_groupnorm_workspace_bytes(p) bytes of device scratch */
+ *   workspace   : flair_groupnorm_workspace_bytes(p) bytes of device scratch
+ *   limits      : C <= 2048 (f32) / 4096 (bf16): one 16-byte channel piece per thread of a <= 512-thread row group
+ *                 (FLAIR_ERR_ARG "too wide" beyond that); C a multiple of 4 (f32) / 8 (bf16). */
 typedef struct {
     int dtype;
     int C, c0;   /* channels in total / in segment 0 */

@@ -83,7 +83,7 @@ def warp_affine_cubic(img, M, dsize, border=(0.0, 0.0, 0.0)):
     for k in range(C):
         P = img[:, :, k]
         cv = T(border[k] if k < len(border) else 0.0)
-        # inner: plain sum, taps in row-major order, in the image's type
+        # inner: row sums added to a running sum (remapBicubic's order), in the image's type
         s_in = None
         # border: cv + sum over in-image taps of (S - cv) * w
         s_bd = np.full((Hd, Wd), cv, dtype=img.dtype)
@@ -91,14 +91,16 @@ def warp_affine_cubic(img, M, dsize, border=(0.0, 0.0, 0.0)):
             yi = sy + r
             yok = (yi >= 0) & (yi < Hs)
             yc = np.clip(yi, 0, Hs - 1)
+            row = None                      # remapBicubic: a row's four taps are summed first, then added to the running sum
             for c in range(4):
                 xi = sx + c
                 ok = yok & (xi >= 0) & (xi < Ws)
                 S = P[yc, np.clip(xi, 0, Ws - 1)]
                 w = (cy[..., r] * cx[..., c]).astype(np.float32).astype(img.dtype)
                 term = S * w
-                s_in = term if s_in is None else s_in + term
+                row = term if row is None else row + term
                 s_bd = np.where(ok, s_bd + (S - cv) * w, s_bd)
+            s_in = row if s_in is None else s_in + row
         res = np.where(inner, s_in, s_bd)
         res = np.where(outside, cv, res)
         out[:, :, k] = res

@@ -91,3 +91,37 @@ def test_bench_refuses_gpus_it_cannot_see():
     text = r.stderr + r.stdout
     assert r.returncode != 0 and ("GPU(s) are visible" in text or "exited with status" in text), text[-2000:]
     assert '"metric"' not in r.stdout
+
+
+def test_bench_launcher_stops_its_ranks_when_signalled(tmp_path):
+    """The rank processes lead their own sessions, so a kill of the launcher's process group misses them: the launcher
+    itself must stop them (and remove its temporary directory) when the driver terminates it."""
+    import signal
+    import time
+    sleeper = tmp_path / "sleeper.py"
+    sleeper.write_text("import os, time\n"
+                       f"open(os.path.join({str(tmp_path)!r}, 'pid_' + os.environ['RANK']), 'w').write(str(os.getpid()))\n"
+                       "time.sleep(120)\n")
+    driver = tmp_path / "driver.py"
+    driver.write_text("import sys\n"
+                      f"sys.path.insert(0, {ROOT!r})\n"
+                      "import bench\n"
+                      f"bench.__file__ = {str(sleeper)!r}\n"
+                      "sys.argv = ['bench.py']\n"
+                      "raise SystemExit(bench.spawn_ranks(2, wall_limit_s=100))\n")
+    p = subprocess.Popen([sys.executable, str(driver)], cwd=ROOT, stderr=subprocess.PIPE, text=True)
+    try:
+        t_end = time.time() + 120
+        while time.time() < t_end and not all((tmp_path / f"pid_{r}").exists() and (tmp_path / f"pid_{r}").read_text()
+                                             for r in range(2)):
+            time.sleep(0.1)
+        pids = [int((tmp_path / f"pid_{r}").read_text()) for r in range(2)]
+        p.send_signal(signal.SIGTERM)
+        _, err = p.communicate(timeout=30)
+    finally:
+        if p.poll() is None:
+            p.kill()
+    assert p.returncode == 128 + signal.SIGTERM, (p.returncode, err[-1000:])
+    for pid in pids:
+        with pytest.raises(ProcessLookupError):
+            os.kill(pid, 0)
