@@ -97,6 +97,11 @@ def parse():
     ap.add_argument("--aux-dtype", default="f32", choices=["f32", "bf16"],
                     help="CodeFormer arithmetic: the reference keeps the prior in fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--attention-resolutions", default=None,
+                    help="comma-separated downsample rates that get spatial attention (unet_new.UNetModel). Default: the "
+                         "reference's 512-pixel tuple scaled with the clip side, (S//32, S//16, S//8) = 8,16,32 at 256 "
+                         "(attention over 1024 / 256 / 64 tokens, as in the 512-pixel network); 16,32,64 = the tuple "
+                         "taken literally (scripts/video_sample.py:122-126; 256 / 64 / 16 tokens at 256, SURVEY.md section 3.2)")
     ap.add_argument("--graph", dest="graph", action="store_true", default=True,
                     help="replay a captured hipGraph of the UNet forward (default): bit-identical to eager launches and "
                          "as fast on one GPU (the step is GPU-bound), but the host spends ~5 ms instead of ~60 ms per "
@@ -325,9 +330,14 @@ def main():
         from flair_amd.guided_diffusion.sr3 import UNet as BicubicUNet
         model = BicubicUNet(**wl.sr3_config(S, use_fp16=(a.dtype == "bf16")))
     else:
-        model = UNetModel(**wl.blur_config(S, use_fp16=(a.dtype == "bf16")))
+        cfg_ = wl.blur_config(S, use_fp16=(a.dtype == "bf16"))
+        if a.attention_resolutions:
+            cfg_["attention_resolutions"] = tuple(int(v) for v in a.attention_resolutions.split(","))
+        model = UNetModel(**cfg_)
+        attn_res = tuple(cfg_["attention_resolutions"])
     if rank == 0:
         wl.randomize_zero_modules(model)
+    n_params = sum(p_.numel() for p_ in model.parameters())
     model = model.to(dev).eval()
     if a.dtype == "bf16":
         model.convert_to_fp16()
@@ -478,13 +488,13 @@ def main():
 
     sig_events = {}
     for fam, dt_name, flops_, nbytes, e0, e1, replay, sig in prof:
-        d = sig_events.setdefault((fam, dt_name, sig), [0, 0.0, flops_, replay, 0.0])
+        d = sig_events.setdefault((fam, dt_name, sig), [0, 0.0, flops_, replay, 0.0, nbytes])
         d[0] += 1
         d[1] += e0.elapsed_time(e1) * 1e3              # raw in-situ events (cross-check only)
     for k_, d in sig_events.items():
         d[4] = replay_us(d[3], d[0]) if REPLAY_MODE != "off" else d[1] / d[0]      # isolated per-launch time of this shape
     per = {}
-    for (fam, dt_name, sig), (n_, ev_us, fl_, replay, us_) in sig_events.items():
+    for (fam, dt_name, sig), (n_, ev_us, fl_, replay, us_, nb_) in sig_events.items():
         d = per.setdefault((fam, dt_name), [0, 0.0, 0.0, 0.0, 0.0])
         d[0] += n_
         d[1] += fl_ * n_
@@ -502,7 +512,7 @@ def main():
     all_secs = sum(per[k][3] for k in conv_keys)
     step_s = elapsed / K
     by_shape = []
-    for (fam, dt_name, sig), (n_, ev_us, fl_, replay, us_) in sig_events.items():
+    for (fam, dt_name, sig), (n_, ev_us, fl_, replay, us_, nb_) in sig_events.items():
         if (fam, dt_name) != key:
             continue
         by_shape.append({"shape": {"T": sig[1], "H": sig[2], "W": sig[3], "cin": list(sig[4]), "cout": sig[5], "kernel": list(sig[6]),
@@ -512,31 +522,44 @@ def main():
     by_shape.sort(key=lambda e_: -e_["launches"] * e_["us_per_launch"])
 
     def family(pred, bound, label):
-        ks = [k for k in per if pred(k[0])]
+        """pred(fam, sig) over the distinct launch shapes; time = sum(count x isolated per-launch time)."""
+        ks = [k for k in sig_events if pred(k[0], k[2])]
         if not ks:
             return None
-        n = sum(per[k][0] for k in ks)
-        fl, by, se = (sum(per[k][i] for k in ks) for i in (1, 2, 3))
+        n = sum(sig_events[k][0] for k in ks)
+        fl = sum(sig_events[k][0] * sig_events[k][2] for k in ks)
+        by = sum(sig_events[k][0] * sig_events[k][5] for k in ks)
+        se = sum(sig_events[k][0] * sig_events[k][4] for k in ks) * 1e-6
         ent = {"family": label, "bound": bound, "launches": n, "ms_per_step": 1e3 * se, "share_of_step": se / step_s}
         if bound == "mfma":
             pk = MFMA_PEAK_TFLOPS["bf16" if "bfloat16" in ks[0][1] else "f32"]
             ent.update(achieved=fl / se / 1e12, peak=pk, unit="TFLOP/s", frac=fl / se / 1e12 / pk)
         else:
             ent.update(achieved=by / se / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=by / se / 1e9 / HBM_PEAK_GBS,
-                       algorithmic_MB_per_launch=by / n / 1e6)
+                       algorithmic_MB_per_launch=by / n / 1e6, TFLOP_per_s=fl / se / 1e12)
         return ent
+
+    def is_1x1(sig):          # a convolution that only moves bytes: 1x1x1 taps, stride 1 (sig: ops.conv's signature)
+        return tuple(sig[6]) == (1, 1, 1) and sig[7] == 1
+
+    def big_level(sig):       # >= 64 x 64 pixels per frame: activations far beyond the L2s, arithmetic intensity <= 2*Cin*Cout/(Cin+Cout)/esz
+        return sig[2] * sig[3] >= 64 * 64
     fams = [
-        family(lambda f: f[0] == "conv" and f[1] in (6, 7, 9, 10), "mfma",
+        family(lambda f, sg: f[0] == "conv" and f[1] in (6, 7, 9, 10), "mfma",
                "per-frame 3x3 convs of the BasicVSR++ recurrence (conv3x3_dma_kernel<8|4 rows> / conv3x3_halo_ks_kernel)"),
-        family(lambda f: f[0] == "conv" and f[1] in (3, 4, 5, 8), "mfma",
+        family(lambda f, sg: f[0] == "conv" and f[1] in (3, 4, 5, 8), "mfma",
                "clip-level 3x3 / 3x3x3 convs + c->432 offset convs (conv3x3_dma_kernel<16 rows> / conv3x3_halo_kernel)"),
-        family(lambda f: f[0] == "conv" and f[1] in (0, 1, 2), "mfma", "1x1 / strided / small-spatial convs (conv_igemm_kernel)"),
-        family(lambda f: f[0] == "chain", "mfma", "fused per-frame conv chains (conv_chain_kernel)"),
-        family(lambda f: f[0] == "gn", "hbm", "GroupNorm+SiLU+FiLM(+resample): gn_partial/finalize/apply, bytes = esz*3*numel"),
-        family(lambda f: f[0] == "dcn" and f[1] <= 64, "hbm", "deformable alignment c=64 (dcn_kernel), bytes = esz*(3c+432)*H*W"),
-        family(lambda f: f[0] == "dcn" and f[1] > 64, "hbm", "deformable alignment c=128 (dcn_kernel), bytes = esz*(3c+432)*H*W"),
-        family(lambda f: f[0] == "prep", "hbm", "flow warp + compose of one propagation step (vsrpp_prep_kernel)"),
-        family(lambda f: f[0] == "attn", "mfma", "spatial QKVAttention in situ (attn_mfma_bf16_kernel; isolated: attention_isolated)"),
+        family(lambda f, sg: f[0] == "conv" and f[1] in (0, 1, 2) and is_1x1(sg) and big_level(sg), "hbm",
+               "1x1 convs on the >= 64x64 levels (conv_igemm_kernel): skip / qkv / proj / conv_last, <= 64 FLOP per byte moved; "
+               "bytes = esz*(Cin+Cout*(1+residuals))*T*H*W"),
+        family(lambda f, sg: f[0] == "conv" and f[1] in (0, 1, 2) and not (is_1x1(sg) and big_level(sg)), "mfma",
+               "strided / 7x7 / deep-K small-spatial convs and 1x1 convs of the <= 32x32 levels (conv_igemm_kernel, split-K)"),
+        family(lambda f, sg: f[0] == "chain", "mfma", "fused per-frame conv chains (conv_chain_kernel)"),
+        family(lambda f, sg: f[0] == "gn", "hbm", "GroupNorm+SiLU+FiLM(+resample): gn_partial/finalize/apply, bytes = esz*3*numel"),
+        family(lambda f, sg: f[0] == "dcn" and f[1] <= 64, "hbm", "deformable alignment c=64 (dcn_kernel), bytes = esz*(3c+432)*H*W"),
+        family(lambda f, sg: f[0] == "dcn" and f[1] > 64, "hbm", "deformable alignment c=128 (dcn_kernel), bytes = esz*(3c+432)*H*W"),
+        family(lambda f, sg: f[0] == "prep", "hbm", "flow warp + compose of one propagation step (vsrpp_prep_kernel)"),
+        family(lambda f, sg: f[0] == "attn", "mfma", "spatial QKVAttention in situ (attn_mfma_bf16_kernel; isolated: attention_isolated)"),
     ]
     fams = [f for f in fams if f]
 
@@ -574,8 +597,10 @@ def main():
                              "note": "isolated replay times; 7 activation passes = SURVEY 8d minimum (0.94 GB at 16x256^2x64 bf16); "
                                      "the unfused pipeline moves 11 (two-pass norm x2, conv read+write x2, residual read)"}
 
-    # ---- north_star target 2: QKVAttention against the MFMA peak, isolated (replay-timed) at L = 256 (config 2's own
-    # attention blocks), 1024 and 4096 tokens; 16 frames, heads of width 64; FLOPs = 4 * frames * heads * L^2 * 64
+    # ---- north_star target 2: QKVAttention against the MFMA peak, isolated (replay-timed) at L = 256, 1024 and 4096 tokens;
+    # 16 frames, heads of width 64; FLOPs = 4 * frames * heads * L^2 * 64.  The benched network (attention_resolutions scaled
+    # with the clip: 8,16,32 at 256) runs its attention blocks at L = 1024 / 256 / 64 like the 512-pixel reference network;
+    # L = 256 is also the LARGEST block of the literal 16,32,64 layout (--attention-resolutions 16,32,64): 1.07 GFLOP, launch-bound
     attention_isolated = []
     if a.dtype == "bf16":
         for L_, C_, heads_ in ((256, 256, 4), (1024, 256, 4), (4096, 128, 2)):
@@ -588,6 +613,15 @@ def main():
                                        "achieved": fl_ / us_ / 1e6, "peak": MFMA_PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
                                        "frac": fl_ / us_ / 1e6 / MFMA_PEAK_TFLOPS["bf16"], "target_frac": 0.50})
             del qkv_, out_
+    # ---- the whole step against the MFMA peak: every FLOP the instrumented steady-state step issued on the matrix cores
+    # (convolutions, fused chains, alignment GEMM + bilinear blends, QK^T / AV) over the timed mean step; SPyNet is not in it
+    # (its flows are cached per clip: not executed in a steady-state step), GroupNorm / warps / sampler count as zero FLOPs.
+    step_flops = sum(d[0] * d[2] for d in sig_events.values())
+    whole_step = {"TFLOP": step_flops / 1e12, "ms": 1e3 * step_s, "achieved": step_flops / step_s / 1e12,
+                  "peak": MFMA_PEAK_TFLOPS[a.dtype if a.dtype in MFMA_PEAK_TFLOPS else "bf16"], "unit": "TFLOP/s",
+                  "frac": step_flops / step_s / 1e12 / MFMA_PEAK_TFLOPS[a.dtype if a.dtype in MFMA_PEAK_TFLOPS else "bf16"],
+                  "launches_profiled": sum(d[0] for d in sig_events.values()),
+                  "sum_of_isolated_family_ms": sum(f["ms_per_step"] for f in fams)}
     traffic, traffic_src = pmc_traffic_for(CONV_ROCPROF.get(key[0][1], ""), dkey)
     ms_per_step = 1e3 * elapsed / K
     value = world * T / (TOTAL_STEPS * elapsed / K)
@@ -598,13 +632,16 @@ def main():
         "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": f"{a.task}-demo, {world} clip(s) x {T} frames x {S}x{S}, "
                                f"{TOTAL_STEPS}-step generalised DDIM (rho={hp['rho']}), "
-                               + ("sr3.UNet random init, SRConv bicubic restore_fn on GPU" if bicubic else
-                                  "unet_new.UNetModel 405.6M params random init, blur x4 restore_fn on GPU")
+                               + (f"sr3.UNet {n_params / 1e6:.1f}M params random init, SRConv bicubic restore_fn on GPU" if bicubic else
+                                  f"unet_new.UNetModel {n_params / 1e6:.1f}M params random init, attention_resolutions="
+                                  f"{','.join(str(v) for v in attn_res)} (spatial attention over "
+                                  f"{'/'.join(str((S // v) ** 2) for v in attn_res)} tokens), blur x4 restore_fn on GPU")
                                + ", one clip per GPU",
                    "steps_per_clip": TOTAL_STEPS, "value_definition": f"n_gpus*frames/({TOTAL_STEPS}*mean timed step)",
                    "finite_output": finite, "weight_broadcast_s": max(b["s"] for b in bcast_per_rank),
                    "weight_broadcast_bytes": bcast_bytes, "weight_broadcast_per_rank": bcast_per_rank,
-                   "hip_graph": use_graph,
+                   "hip_graph": use_graph, "params_M": n_params / 1e6,
+                   "attention_resolutions": None if bicubic else list(attn_res),
                    "aux_prior": "identity" if a.aux == "identity" else f"CodeFormer (HIP, {a.aux_dtype}) every step t >= tau"},
         "roofline": {"bound": "mfma", "kernel": CONV_VARIANTS.get(key[0][1], str(key[0][1])) + " " + key[1],
                      "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
@@ -618,6 +655,7 @@ def main():
                      "by_shape": by_shape,
                      "all_conv_achieved": all_flops / all_secs / 1e12,
                      "all_conv_share_of_step": all_secs / (ms_per_step * 1e-3),
+                     "whole_step": whole_step,
                      "resblock_path": resblock_path,
                      "attention_isolated": attention_isolated,
                      "families": fams},

@@ -147,8 +147,8 @@ def test_config1_gaussian_8x128_f32_vs_oracle(dev):
                + ", ".join(f"{(b.cpu() - a).abs().max().item() / a.abs().max().item():.2e}" for a, b in zip(ref_eps, got_eps)))
 
     # ---- the BENCHMARKED dtype on the same inputs: the bf16 full-width network (same weights) against the fp32 oracle
-    # forward that is already computed.  Stated bound: every stage within 6e-2 of its max magnitude, the network output
-    # (eps | v) within 6e-2 of its max and 4e-2 of its rms (measured 3.4e-2 / 3.4e-2 / 2.1e-2) (bf16 storage between ~250 layers; measured values go to profiles/r03_parity.txt).
+    # forward that is already computed.  Stated bound: every stage within 5e-2 of its max magnitude, the network output
+    # (eps | v) within 5e-2 of its max and 3.2e-2 of its rms (~1.5x the measured 3.1-3.4e-2 / 2.5-3.4e-2 / 2.1e-2 of rounds 3-4) (bf16 storage between ~250 layers; measured values go to profiles/r04_parity.txt).
     del m
     torch.cuda.empty_cache()
     mb = UNetModel(**wl.blur_config(S, use_fp16=True))
@@ -170,10 +170,10 @@ def test_config1_gaussian_8x128_f32_vs_oracle(dev):
     worst = max(rep_b, key=lambda r: r[1])
     parity_log(f"config1 8x128 full-width (405.6M) bf16 kernels vs fp32 oracle: worst stage {worst[0]} {worst[1]:.2e} of its max, "
                f"median stage {sorted(r[1] for r in rep_b)[len(rep_b) // 2]:.2e}; network output max-err {e_out:.2e} of max, "
-               f"rms-err {e_rms:.2e} of rms (bounds 6e-2 / 6e-2 / 4e-2)")
-    bad = [r for r in rep_b if r[1] > 6e-2]
-    assert not bad, f"bf16 stages beyond 6e-2: {bad[:4]}"
-    assert e_out <= 6e-2 and e_rms <= 4e-2, (e_out, e_rms)
+               f"rms-err {e_rms:.2e} of rms (bounds 5e-2 / 5e-2 / 3.2e-2)")
+    bad = [r for r in rep_b if r[1] > 5e-2]
+    assert not bad, f"bf16 stages beyond 5e-2: {bad[:4]}"
+    assert e_out <= 5e-2 and e_rms <= 3.2e-2, (e_out, e_rms)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -311,11 +311,11 @@ def _oracle_chain():
 # tape), abs on [-1,1] data: (final sample, worst intermediate x_t relative to max(1, |x_t|)).
 #   f32 kernels : 2e-3 / 5e-3  (per-step network error <= 2e-4, amplified by up to sqrt(1/acp - 1) = 157 in x0 at the
 #                 first steps, clipped, contracting as the chain proceeds; measured 2-6e-4)
-#   bf16 kernels: 1.5e-1 / 1.5e-1 max, 1.5e-2 rms  (the benchmarked dtype: bf16 storage between layers, f32 accumulation /
+#   bf16 kernels: 1.0e-1 / 1.0e-1 max, 7.5e-3 rms (~1.5x the measured 6.1-6.9e-2 / 4.8e-3)  (the benchmarked dtype: bf16 storage between layers, f32 accumulation /
 #                 statistics / sampler; measured 6.9e-2 max at isolated pixels of the last step, 4.8e-3 rms:
-#                 profiles/r03_parity.txt)
-CHAIN_TOL = {torch.float32: (2e-3, 5e-3), torch.bfloat16: (1.5e-1, 1.5e-1)}
-CHAIN_RMS_TOL = {torch.float32: 2e-4, torch.bfloat16: 1.5e-2}
+#                 profiles/r03_parity.txt, r04_parity.txt)
+CHAIN_TOL = {torch.float32: (2e-3, 5e-3), torch.bfloat16: (1.0e-1, 1.0e-1)}
+CHAIN_RMS_TOL = {torch.float32: 2e-4, torch.bfloat16: 7.5e-3}
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

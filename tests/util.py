@@ -37,14 +37,14 @@ def assert_close(got, ref, dtype, what="", scale=1.0):
 
 
 def parity_log(line):
-    """Append one measured-error line to gpurun_out/r03_parity.txt (merged back from the GPU box; the copy under
+    """Append one measured-error line to gpurun_out/r04_parity.txt (merged back from the GPU box; the copy under
     profiles/ is the committed record).  Never fails a test."""
     import os
     try:
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         d = os.path.join(root, "gpurun_out")
         os.makedirs(d, exist_ok=True)
-        with open(os.path.join(d, "r03_parity.txt"), "a") as f:
+        with open(os.path.join(d, "r04_parity.txt"), "a") as f:
             f.write(line.rstrip() + "\n")
     except OSError:
         pass
