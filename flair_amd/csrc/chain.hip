@@ -25,6 +25,8 @@
 //   * stage B reads its B operands straight from that LDS tile.
 // MFMA operand roles, the 80-byte LDS pitch (conflict-free ds_read_b128) and the tap loop are those of
 // conv3x3_halo_kernel (conv.hip); a work item is 32 pixels x 64 output channels on one wavefront.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -465,6 +467,315 @@ __global__ __launch_bounds__(512, 2) void conv_chain_kernel(ChainArgs a) {
     STAMP(6);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Input-resident 3x3 convolution with many output channels, LDS-DMA weight ring (round 4): the c -> 27*G offset
+// convolution of SecondOrderDeformableAlignment at c = 64 (unet_new.py:859-867 conv_offset[6]; 32.6 GFLOP per 256^2 frame,
+// 150 launches per step).  The form above (HASA = false) staged each (64-cout block, 32-channel chunk) of the weights through
+// registers (load -> ds_write -> barrier -> multiply -> barrier: two barriers and a 46 KB LDS write pass per 36 MFMAs of a
+// wave) and ran the tanh / sigmoid epilogue of a block with nothing beside it: 48.7 us per launch = 0.27 of the MFMA peak.
+// Here:
+//   * the (8+2) x 34 pixel halo of all 64 input channels is brought in ONCE by LDS-DMA (two 64-byte-row images, one per
+//     32-channel chunk, 16-byte pieces XOR-swizzled on the source address like conv3x3_dma_kernel);
+//   * the weights stream through a ring of three 36 KB stages (one stage = 64 couts x 9 taps x 32 channels), stages s + 1 and
+//     s + 2 in flight by LDS-DMA while stage s is multiplied, ONE barrier per stage, counted vmcnt;
+//   * two accumulator sets alternate between consecutive 64-cout blocks: the epilogue of block b (bias from LDS, activation,
+//     v_permlane32_swap -> 16-byte buffer stores) is issued in four pieces BETWEEN the taps of block b + 1's MFMAs, where the
+//     vector ALU is otherwise idle; only the last block's epilogue is exposed.
+// A wave owns one image row (32 pixels) of the 8 x 32 tile x the 64 couts of the current block.  bf16, C = 64, W % 32 == 0,
+// H % 8 == 0, no residual inputs.
+struct ResArgs {
+    const void* x; int xLd; unsigned xBytes;      // one input frame
+    const void* w; unsigned wBytes;               // [Cout][9][64]
+    const float* bias;
+    int Cout, act;
+    float actParam; int actPeriod;
+    float outScale;
+    void* y; int yLd;
+    int T, H, W;
+    int debug;            // phase switches of the diagnostic build (-DFLAIR_TIMING_SWITCHES): 1 no MFMA phase, 2 no weight DMA after
+                          // the prologue, 3 no epilogue, 4 return after the prologue
+};
+#ifdef FLAIR_TIMING_SWITCHES
+#define RES_DBG(a) ((a).debug)
+#else
+#define RES_DBG(a) 0
+#endif
+
+// NW wavefronts per workgroup, each owning RPW = 8 / NW image rows (32 pixels each) x the 64 couts of the current block:
+//   <8 waves x 1 row>: 6 fragment reads per 4 MFMAs (1.5 ds_read_b128 per MFMA: three quarters of the LDS read rate at the full
+//                      matrix rate), two waves per SIMD;
+//   <4 waves x 2 rows>: the (RPW + 2) halo rows of a column tap are read once for its three row taps and a weight fragment
+//                      serves both rows: 20 reads per 24 MFMAs (0.83), one wave per SIMD with up to 512 registers.
+template <int ACT, int NW>      // ACT 0: max(v, slope v) (none / ReLU / LeakyReLU)   1: DCN offsets / masks   2: SiLU
+__global__ __launch_bounds__(64 * NW, NW / 4) void conv_resident_kernel(ResArgs a) {
+    prefetch_kernargs<sizeof(ResArgs)>();
+    using E = bf16_t;
+    constexpr int RPW = 8 / NW;
+    constexpr int HWP = 34, HROWS = 10 * HWP, HINSTR = (HROWS + 15) / 16, HBYTES = HINSTR * 1024;    // 22 KB per chunk image
+    constexpr int WINSTR = 36, SLOT = WINSTR * 1024, NRING = 3;
+    constexpr int RING = 2 * HBYTES, BIAS = RING + NRING * SLOT;                                      // + 2 KB of f32 biases
+    constexpr int NH = (HINSTR + NW - 1) / NW, NWS = (WINSTR + NW - 1) / NW;    // DMA instructions per wave: one halo chunk image, one weight stage
+    constexpr int NST = 2 * RPW;                    // epilogue stores per wave and stage (4 groups x RPW rows per block)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int lrow = lane >> 2, lchunk = lane & 3;
+    const int tilesW = a.W / 32, perFrame = tilesW * (a.H / 8);
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int t = bid / perFrame, tile = bid - t * perFrame;
+    const int h0 = (tile / tilesW) * 8, w0 = (tile % tilesW) * 32;
+    const int nBlk = (a.Cout + 63) >> 6, nS = 2 * nBlk;
+
+    const unsigned ldB = (unsigned)a.xLd * 2u;
+    const u32x4_t xdesc = make_desc(reinterpret_cast<const char*>(a.x) + (size_t)t * a.H * a.W * ldB, a.xBytes);
+    const u32x4_t wdesc = make_desc(a.w, a.wBytes);
+    const u32x4_t bdesc = make_desc(a.bias, a.bias ? (unsigned)a.Cout * 4u : 0u);
+
+    // ---- prologue DMA, in the order of first use: biases (waves duplicate the two 1 KB pieces), halo chunk 0, weight stage 0,
+    // halo chunk 1, weight stage 1 -- stage 0 needs only the first three, so the first wait leaves chunk 1 and stage 1 in flight.
+    // Every wave issues the same number of instructions per phase (surplus ids repeat earlier ones: same bytes to the same
+    // place), so that one immediate vmcnt serves all waves.
+    dma16(bdesc, (unsigned)((wave & 1) * 1024 + lane * 16), (unsigned)(BIAS + (wave & 1) * 1024));
+    auto issue_halo = [&](int ch) {
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+            const int k = (wave * NH + i) % HINSTR;
+            const int R = k * 16 + lrow;
+            const int hr = R / HWP, c = R - hr * HWP;
+            const int hh = h0 - 1 + hr, ww = w0 - 1 + c;
+            const bool ok = R < HROWS && (unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W;
+            const unsigned voff = ok ? (unsigned)(hh * a.W + ww) * ldB + (unsigned)(ch * 64) + (unsigned)((lchunk ^ ((c >> 2) & 3)) << 4) : FLAIR_OOB;
+            dma16(xdesc, voff, (unsigned)(ch * HBYTES + k * 1024));
+        }
+    };
+    issue_halo(0);
+    // weight slots of this wave: instruction ids (wave * NWS + i) % 36; lane part of the source offset and its cout inside the block
+    unsigned wlane[NWS];
+    int wco[NWS];
+#pragma unroll
+    for (int i = 0; i < NWS; ++i) {
+        const int id = (wave * NWS + i) % WINSTR;
+        const int row = id * 16 + lrow, tap9 = row >> 6, co = row & 63;
+        wlane[i] = (unsigned)((co * 9 + tap9) * 64) * 2u + (unsigned)((lchunk ^ ((co >> 2) & 3)) << 4);
+        wco[i] = co;
+    }
+    auto issue_w = [&](int s_) {                                    // stage s_ = (block, chunk) -> ring slot s_ % 3
+        const int blk = s_ >> 1, ch = s_ & 1;
+        const unsigned base = (unsigned)(blk * 64 * 9 * 64) * 2u + (unsigned)(ch * 64);
+        const unsigned dst = (unsigned)(RING + (s_ % NRING) * SLOT);
+#pragma unroll
+        for (int i = 0; i < NWS; ++i) {
+            const int id = (wave * NWS + i) % WINSTR;
+            dma16(wdesc, blk * 64 + wco[i] < a.Cout ? base + wlane[i] : FLAIR_OOB, dst + (unsigned)(id * 1024));
+        }
+    };
+    issue_w(0);
+    issue_halo(1);
+    if (nS > 1) issue_w(1);
+
+    // ---- fragment read offsets (per lane, fixed): A = weight row tap9 * 64 + cf * 32 + lr, B = halo row (RPW wave + h) * 34 + kw + lr
+    unsigned aoff[2], boff[3][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        aoff[ks] = (unsigned)(lr * 64 + (((2 * ks + lh) ^ ((lr >> 2) & 3)) << 4));
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+            boff[kw][ks] = (unsigned)((RPW * wave * HWP + kw + lr) * 64 + (((2 * ks + lh) ^ (((kw + lr) >> 2) & 3)) << 4));
+    }
+
+    // ---- epilogue of one 64-cout block, one (row, 16-cout group) piece at a time (all lanes take part in the swaps).  The
+    // accumulators start at the bias.  DCN offsets / masks: out = A * rcp(1 + 2^(k v)) + B with per-lane constants
+    // (residues: mag * tanh(v) = mag - 2 mag / (1 + e^{2v}); masks: 1 / (1 + e^{-v})), three vector and two transcendental
+    // instructions per value.
+    const float slope = a.act == FLAIR_ACT_NONE ? 1.f : a.act == FLAIR_ACT_RELU ? 0.f : 0.1f;
+    const unsigned yLdB = (unsigned)a.yLd * 2u;
+    const long prow = ((long)t * a.H + h0 + RPW * wave) * a.W + w0;        // first pixel of the wave's first row
+    const __amdgpu_buffer_rsrc_t yd = make_rsrc(reinterpret_cast<char*>(a.y) + prow * a.yLd * 2, (unsigned)(RPW * a.W) * yLdB);
+    const unsigned yLane = (unsigned)lr * yLdB + 16u * lh;
+    const float* sbias = reinterpret_cast<const float*>(smem + BIAS);
+    const float scale = a.outScale;
+    auto epi_piece = [&](const f32x16 (&accE)[RPW][2], int blk, int piece) {
+        const int j = piece / 4, g = piece % 4;
+        const int i = g >> 1, jj = g & 1;
+        const int co = blk * 64 + i * 32 + 16 * jj;                  // first cout of the group (wave-uniform); this lane: + 8 * lh
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const auto sw2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(accE[j][i][8 * jj + e]), __float_as_uint(accE[j][i][8 * jj + 4 + e]), false, false);
+            v[e] = __uint_as_float(sw2[0]);
+            v[4 + e] = __uint_as_float(sw2[1]);
+        }
+        if constexpr (ACT == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], v[e] * slope) * scale;
+        } else if constexpr (ACT == 1) {
+            const bool residue = 3 * ((co + 8 * lh) % a.actPeriod) < 2 * a.actPeriod;
+            const float kk = residue ? 2.885390081777927f : -1.4426950408889634f;       // 2 log2(e) | -log2(e)
+            const float A = residue ? -2.f * a.actParam * scale : scale, B = residue ? a.actParam * scale : 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaf(__builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(kk * v[e])), A, B);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= scale * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v[e]));
+        }
+        alignas(16) E out[8];
+        Vec16<E>::store(out, v);
+        const uint4 ov = *reinterpret_cast<const uint4*>(out);
+        const unsigned yo = co + 8 * lh < a.Cout ? yLane + (unsigned)(j * a.W) * yLdB + 2u * (unsigned)co : FLAIR_OOB;
+        // (plain stores: write-through `sc1` / `sc0 sc1` stores measured 176-177 us against 178.6 us on the conv_offset[6] ->
+        // alignment pair, non-temporal ones 188 us: profiles/README.md, round 4)
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{ov.x, ov.y, ov.z, ov.w}, yd, (int)yo, 0, 0);
+    };
+
+    // ---- one stage = 3 column taps x 3 row taps x (RPW rows x 2 cout fragments x 2 k-steps) MFMAs.  The fragments of step n + 1
+    // (A: 4 reads; B: 2 (RPW + 2) more when the column tap changes) are requested before the MFMAs of step n;
+    // `hook(step)` runs after the MFMAs of a step have been issued (pieces of the previous block's epilogue).
+    auto compute = [&](int slot, int ch, f32x16 (&acc)[RPW][2], auto&& hook) {
+        const char* wb = smem + RING + slot * SLOT;
+        const char* xb = smem + ch * HBYTES;
+        uint4 fb[2][RPW + 2][2];   // [set][halo row RPW wave + h][k-step]
+        uint4 fa[2][2][2];         // [set][cout fragment][k-step]
+        auto load_b = [&](int set, int kw) {
+#pragma unroll
+            for (int h = 0; h < RPW + 2; ++h)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    fb[set][h][ks] = *reinterpret_cast<const uint4*>(xb + h * (HWP * 64) + boff[kw][ks]);
+        };
+        auto load_a = [&](int set, int kh, int kw) {
+#pragma unroll
+            for (int cf = 0; cf < 2; ++cf)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    fa[set][cf][ks] = *reinterpret_cast<const uint4*>(wb + (kh * 3 + kw) * 4096 + cf * 2048 + aoff[ks]);
+        };
+        load_b(0, 0);
+        load_a(0, 0, 0);
+#pragma unroll
+        for (int step = 0; step < 9; ++step) {
+            const int kq = step / 3, kh = step % 3;
+            const int nkq = (step + 1) / 3, nkh = (step + 1) % 3;
+            if (step < 8) {
+                if (nkh == 0) load_b(nkq & 1, nkq);
+                load_a((step + 1) & 1, nkh, nkq);
+            }
+#pragma unroll
+            for (int j = 0; j < RPW; ++j)
+#pragma unroll
+                for (int cf = 0; cf < 2; ++cf) {
+                    acc[j][cf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[step & 1][cf][0]),
+                                                                         __builtin_bit_cast(bf16x8, fb[kq & 1][j + kh][0]), acc[j][cf], 0, 0, 0);
+                    acc[j][cf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[step & 1][cf][1]),
+                                                                         __builtin_bit_cast(bf16x8, fb[kq & 1][j + kh][1]), acc[j][cf], 0, 0, 0);
+                }
+            hook(step);
+        }
+    };
+    // accumulators of a block start at its biases (register r of a fragment <-> cout 8 (r / 4) + 4 lh + r % 4)
+    auto init_acc = [&](f32x16 (&acc)[RPW][2], int blk) {
+#pragma unroll
+        for (int cf = 0; cf < 2; ++cf)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bq = *reinterpret_cast<const float4*>(sbias + blk * 64 + cf * 32 + 8 * q + 4 * lh);
+#pragma unroll
+                for (int j = 0; j < RPW; ++j) {
+                    acc[j][cf][4 * q] = bq.x; acc[j][cf][4 * q + 1] = bq.y; acc[j][cf][4 * q + 2] = bq.z; acc[j][cf][4 * q + 3] = bq.w;
+                }
+            }
+    };
+    // wait until weight stage s_ (and everything older: halo, biases) has landed for this wave.  Younger operations at this point:
+    // the epilogue stores of the two previous stages (NST each once block 1 has started) and the DMA of stage s_ + 1 (NWS).
+    auto wait_stage = [&](int s_) {
+        if (s_ + 1 >= nS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (s_ == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NH + NWS) : "memory");       // halo chunk 1 and stage 1 stay in flight
+        else if (s_ <= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWS) : "memory");
+        else if (s_ == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWS + NST) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWS + 2 * NST) : "memory");
+    };
+
+    f32x16 acc0[RPW][2], acc1[RPW][2];
+    // one block = two stages; `accP` accumulates block blk, the epilogue of `accQ` (block blk - 1) runs beside it
+    auto block = [&](int blk, f32x16 (&accP)[RPW][2], f32x16 (&accQ)[RPW][2]) {
+        const bool prev = blk > 0;
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            const int s_ = 2 * blk + ch;
+            wait_stage(s_);
+            __builtin_amdgcn_s_barrier();            // stage s_ is in LDS for everybody; everybody is done with stage s_ - 1
+            if (s_ + 2 < nS && RES_DBG(a) != 2) issue_w(s_ + 2);        // ring slot (s_ + 2) % 3 = (s_ - 1) % 3 is free
+            if (RES_DBG(a) == 4) return;
+            if (ch == 0) init_acc(accP, blk);        // (the biases landed with the first stage)
+            if (RES_DBG(a) == 1) continue;
+            if (prev && RES_DBG(a) != 3) {
+                compute(s_ % NRING, ch, accP, [&](int step) {
+                    // 4 RPW pieces per block, 2 RPW per stage, spread over the nine steps
+                    if constexpr (RPW == 1) {
+                        if (step == 1) epi_piece(accQ, blk - 1, 2 * ch);
+                        if (step == 5) epi_piece(accQ, blk - 1, 2 * ch + 1);
+                    } else {
+                        if (step == 0 || step == 2 || step == 4 || step == 6) epi_piece(accQ, blk - 1, 4 * ch + step / 2);
+                    }
+                });
+            } else {
+                compute(s_ % NRING, ch, accP, [](int) {});
+            }
+        }
+    };
+    for (int blk = 0; blk < nBlk; blk += 2) {
+        block(blk, acc0, acc1);
+        if (blk + 1 < nBlk) block(blk + 1, acc1, acc0);
+    }
+    // the last block's epilogue is exposed
+    if (RES_DBG(a) == 3) {
+#pragma unroll
+        for (int j = 0; j < RPW; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc0[j][0][r]), "v"(acc0[j][1][r]), "v"(acc1[j][0][r]), "v"(acc1[j][1][r]));
+        return;
+    }
+    if (nBlk & 1) {
+#pragma unroll
+        for (int g = 0; g < 4 * RPW; ++g) epi_piece(acc0, nBlk - 1, g);
+    } else {
+#pragma unroll
+        for (int g = 0; g < 4 * RPW; ++g) epi_piece(acc1, nBlk - 1, g);
+    }
+}
+
+int launch_resident(const ChainArgs& c, hipStream_t s) {
+    ResArgs a;
+    a.x = c.x[0]; a.xLd = c.segLd[0]; a.xBytes = c.segBytes[0];
+    a.w = c.wB; a.wBytes = c.wBBytes; a.bias = c.biasB; a.Cout = c.CoutB; a.act = c.actB;
+    a.actParam = c.actParam; a.actPeriod = c.actPeriod; a.outScale = c.outScale;
+    a.y = c.y; a.yLd = c.yLd; a.T = c.T; a.H = c.H; a.W = c.W;
+    a.debug = 0;
+#ifdef FLAIR_TIMING_SWITCHES
+    a.debug = getenv("FLAIR_RES_DEBUG") ? atoi(getenv("FLAIR_RES_DEBUG")) : 0;
+#endif
+    constexpr size_t lds = 2 * 22 * 1024 + 3 * 36 * 1024 + 2048;
+    const int grid = a.T * (a.H / 8) * (a.W / 32);
+    // FLAIR_CONV_RESIDENT_WAVES = 4: four waves of two rows (default: eight waves of one row; same-box step 81.7 vs 82.1 ms)
+    static const int nw = getenv("FLAIR_CONV_RESIDENT_WAVES") ? atoi(getenv("FLAIR_CONV_RESIDENT_WAVES")) : 8;
+    auto go = [&](auto tag, auto nwTag) -> int {
+        constexpr int ACT = decltype(tag)::value, NW = decltype(nwTag)::value;
+        static LdsAttrOnce attr;
+        const hipError_t e = flair_max_lds_once(attr, reinterpret_cast<const void*>(&conv_resident_kernel<ACT, NW>));
+        FLAIR_CHECK(e == hipSuccess, "flair_conv_chain: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL((conv_resident_kernel<ACT, NW>), dim3(grid), dim3(64 * NW), lds, s, a);
+        FLAIR_LAUNCH_CHECK();
+        return FLAIR_OK;
+    };
+    auto pick = [&](auto tag) -> int {
+        return nw == 8 ? go(tag, std::integral_constant<int, 8>{}) : go(tag, std::integral_constant<int, 4>{});
+    };
+    if (a.act == FLAIR_ACT_DCN_OFFSETS) return pick(std::integral_constant<int, 1>{});
+    if (a.act == FLAIR_ACT_SILU) return pick(std::integral_constant<int, 2>{});
+    return pick(std::integral_constant<int, 0>{});
+}
+
 template <typename E, int C, int TH, int TW, bool HASA>
 int launch_chain(const ChainArgs& a, hipStream_t s) {
     constexpr int BKE = MmaC<E>::BKE;
@@ -554,6 +865,14 @@ extern "C" int flair_conv_chain(const flair_chain_params* p, const void* const* 
 #ifdef FLAIR_CHAIN_STAMPS
     if (const char* e = getenv("FLAIR_CHAIN_DBG_PTR")) a.dbg = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 16));
 #endif
+    // round 4: the input-resident LDS-DMA form for the wide-output convolution without stage A (the c -> 27*G offset convolution)
+    {
+        static const bool useRes = !(getenv("FLAIR_CONV_RESIDENT") && atoi(getenv("FLAIR_CONV_RESIDENT")) == 0);
+        if (useRes && !hasA && p->dtype == FLAIR_BF16 && p->C == 64 && p->W % 32 == 0 && p->H % 8 == 0 && !res0 && !res1 &&
+            (p->y_ld * 2) % 16 == 0 && p->CoutB % 8 == 0 &&
+            (unsigned long long)p->H * p->W * p->y_ld * 2 < 0x40000000ull)
+            return launch_resident(a, stream);
+    }
     // partial tiles in H are masked (hh < H); tile widths (32 or 8) divide W by the check above
     if (p->dtype == FLAIR_BF16)
         return hasA ? dispatch_chain<bf16_t, true>(a, p->C, stream) : dispatch_chain<bf16_t, false>(a, p->C, stream);

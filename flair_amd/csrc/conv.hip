@@ -982,29 +982,6 @@ struct DmaTile {
     int t, h0, w0, co0;
 };
 
-// One LDS-DMA wave instruction: 64 lanes x 16 bytes from `desc` (buffer descriptor words in SGPRs) at per-lane byte
-// offset `voff` (out-of-range offsets deliver zeros) to LDS bytes [ldsAddr, ldsAddr + 1024).  Inline asm so that hipcc
-// neither counts it in its own vmcnt bookkeeping nor waits for it ahead of unrelated ds_reads (it drains every LDS-DMA
-// before the next LDS read it cannot tell apart from the DMA's target; cdna_hip_programming.md section 5, trap (a)): the
-// kernel waits with its own `s_waitcnt vmcnt(0)` before the barrier that publishes a stage.  M0 is saved and restored.
-__device__ __forceinline__ void dma16(u32x4_t desc, unsigned voff, unsigned ldsAddr) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(ldsAddr), "s"(desc)
-                 : "memory");
-}
-
-__device__ __forceinline__ u32x4_t make_desc(const void* base, unsigned bytes) {
-    const unsigned long long b = reinterpret_cast<unsigned long long>(base);
-    u32x4_t d;
-    d.x = __builtin_amdgcn_readfirstlane((unsigned)b);
-    d.y = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32) & 0xffffu);
-    d.z = __builtin_amdgcn_readfirstlane(bytes);
-    d.w = 0x00020000u;
-    return d;
-}
-
 // NW wavefronts per workgroup, RPW image rows per wavefront (tile = NW * RPW rows x 32 pixels x 64 couts):
 //   <8, 2> clip-level launches (the shape described above);
 //   <8, 1> / <4, 1> single-round launches of 256 tiles of 8 / 4 rows = the per-frame convolutions of the BasicVSR++

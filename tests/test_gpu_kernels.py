@@ -497,6 +497,36 @@ def test_dcn_offset_activation_epilogue(dev, dtype, path):
     assert_close(from_clip(y), ref, dtype, f"dcn offset activation ({path})", scale=2.0)
 
 
+@pytest.mark.parametrize("cout,act,shape", [(432, 4, (1, 16, 32)), (432, 4, (2, 24, 64)), (64, 2, (1, 8, 32)), (200, 0, (3, 8, 96)),
+                                            (8, 1, (1, 16, 32)), (72, 3, (1, 32, 32)), (432, 4, (1, 128, 128))])
+def test_conv_resident_input(dev, cout, act, shape):
+    """conv_resident_kernel (round 4: flair_conv_chain without a first stage on bf16 c = 64 inputs -- the c -> 27*G offset
+    convolution): halo resident in LDS, weight ring by LDS-DMA, epilogue of block b beside the MFMAs of block b + 1.
+    Odd block counts, a partial last block, one-block outputs, every activation class, several frames; against F.conv2d."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    T, H, W = shape
+    cin, G = 64, 16
+    g = torch.Generator().manual_seed(100 + cout + H)
+    x = rb(torch.randn(T, cin, H, W, generator=g), dtype)
+    w = rb(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin) * (3 if act == 4 else 1), dtype)
+    b = torch.randn(cout, generator=g) * 0.3
+    pre = F.conv2d(x, w, b, padding=1)
+    if act == 4:
+        residue = (torch.arange(cout) % (3 * G)) < 2 * G
+        ref = torch.where(residue.view(1, -1, 1, 1), 10 * torch.tanh(pre), torch.sigmoid(pre))
+    else:
+        ref = {0: lambda v: v, 1: torch.relu, 2: lambda v: F.leaky_relu(v, 0.1), 3: F.silu}[act](pre)
+    ref = ref * 0.75
+    wp = ops.pack_conv_weight(w[:, :, None], [(cin, cin)], dtype).to(dev)
+    y = torch.full((T, H, W, cout + 8), 7.0, dtype=dtype, device=dev)          # a wider buffer: the pad channels must stay untouched
+    ops.conv_chain(to_clip(x, dtype, dev), None, None, 0, wp, b.to(dev), act, cin, cout, out=y, out_scale=0.75,
+                   act_param=10.0 if act == 4 else 0.0, act_period=3 * G if act == 4 else 0)
+    torch.cuda.synchronize()
+    assert torch.all(y[..., cout:] == 7.0)
+    assert_close(from_clip(y[..., :cout]), ref, dtype, f"resident-input conv cout={cout} act={act}", scale=2.0)
+
+
 def test_embedding_linear_layout(dev):
     from oracle.unet import timestep_embedding
     ops = _ops()

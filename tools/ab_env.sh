@@ -1,14 +1,16 @@
-# Same-box A/B of one environment switch on the headline bench:  bash tools/ab_env.sh <out> <rounds> VAR=value   (against the default)
+#!/bin/bash
+# Same-box A/B of the headline bench over environment switches:  bash tools/ab_env.sh <outdir> "VAR=a" "VAR=b" ...  (each setting run twice, interleaved)
 set -o pipefail
 export PYTHONPATH=$PWD
-OUT=$1; R=$2; SW=$3
+OUT=$1; shift
 mkdir -p $OUT
-for r in $(seq $R); do
-  for mode in switch default; do
-    if [ $mode = switch ]; then E="$SW"; else E="FLAIR_NOOP=1"; fi
-    env $E timeout -k 10 300 python bench.py --steps 30 --warmup 3 --no-cpu-baseline 2>>$OUT/err.log | python -c "
+run() {
+  env $1 timeout -k 10 300 python bench.py --steps ${STEPS:-40} --warmup 3 --no-cpu-baseline 2>>$OUT/err.log | tail -1 > $OUT/last.json
+  python - "$1" $OUT/last.json <<'PY' | tee -a $OUT/ab.log
 import json,sys
-l=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('$mode ($SW)', round(l['ms_per_step'],2), 'ms/step')" | tee -a $OUT/bench.log
-  done
-done
+l=json.load(open(sys.argv[2]))
+fam={f['family'][:28]:round(f['ms_per_step'],2) for f in l['roofline']['families']}
+print(sys.argv[1], '->', round(l['ms_per_step'],2), 'ms/step', fam)
+PY
+}
+for rep in 1 2; do for s in "$@"; do run "$s"; done; done
