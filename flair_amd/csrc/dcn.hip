@@ -112,9 +112,14 @@ __device__ __forceinline__ float fast_tanh(float x) {
 // buffer resources cover exactly one frame, so rows above / below the image fall outside the resource and read 0
 // by the hardware range check; columns left / right of it get weight 0.  That removes the per-corner address
 // selects of the general path (the kernel is VALU-issue bound: ~75 % VALU-active, profiles/r02b_dcn_pmc_sq.txt).
+// DOT2 (bf16, round 4): the four-corner blend on v_dot2c_f32_bf16 -- corner pairs of one channel packed by v_perm_b32 against the
+// pair of bilinear weights rounded to bf16 (f32 accumulation): 38 vector instructions per 8 channels instead of 52 (32 bf16 -> f32
+// unpacks + 16 v_pk_fma_f32, which issue at 1.4x the cost of a plain instruction: tools/probes/valu_rate_probe.hip).  The weights lose
+// 16 mantissa bits: |error| <= 2^-9 * sum_k |w_k v_k| <= 2^-9 max|v| per blended value, the size of the bf16 rounding the value gets
+// anyway when it is staged for the MFMA; f32 tensors keep the exact path.
 // PFD = gather register sets in flight (2: the loads of step k+1 fly while step k is blended; 3: also step k+2 --
 // for the c = 128 tiles, where only 8 wavefronts per CU exist to hide the gather round trip).
-template <typename E, int NCF, int NPF, int TPP, bool ACTIVATED, bool ONEFRAME, int PFD>
+template <typename E, int NCF, int NPF, int TPP, bool ACTIVATED, bool ONEFRAME, int PFD, bool DOT2>
 __global__ __launch_bounds__(32 * NPF * TPP, (NCF >= 4 ? 32 * NPF * TPP / 256 : 4)) void dcn_kernel(DcnArgs a) {
     prefetch_kernargs<sizeof(DcnArgs)>();
     constexpr int NT = 32 * NPF * TPP, NW = NT / 64;
@@ -216,6 +221,7 @@ __global__ __launch_bounds__(32 * NPF * TPP, (NCF >= 4 ? 32 * NPF * TPP / 256 : 
     int itap = 0, icb = 0, ikh = 0, ikw = 0;   // K-loop position of the NEXT issue (block uniform)
     const int rawRow = srow * rawPitch;        // this thread's pixel inside a staged raw slab
     const float fH = (float)a.H, fW = (float)a.W;
+    const float phm1 = (float)(ph - 1), pwm1 = (float)(pw - 1);
     auto issue = [&](Regs& r) {
         const int tap = itap, cb = icb;
         const int c = cb * BKE + q * VEC;
@@ -223,9 +229,12 @@ __global__ __launch_bounds__(32 * NPF * TPP, (NCF >= 4 ? 32 * NPF * TPP / 256 : 
         const E* myraw = reinterpret_cast<const E*>(sraw + (tap & 1) * TP * rawPitch + rawRow);
         const float ry = ET<E>::ld(myraw + 2 * g), rx = ET<E>::ld(myraw + 2 * g + 1);
         const float rm = ET<E>::ld(myraw + 2 * G + g);
-        const float2 fl = g < G / 2 ? fl1 : fl2;
+        // groups below G/2 take flow1, the others flow2; a K step lies in one input half (halfC % BKE == 0), so this is the
+        // block-uniform `second` below
+        const bool second = cb * BKE >= halfC;                // block-uniform (halfC % BKE == 0)
+        const float2 fl = second ? fl2 : fl1;
         // ACTIVATED (compile time): the residues and the mask are used as stored, no transcendental per group
-        float sy = (float)(ph - 1 + ikh) + fl.y, sx = (float)(pw - 1 + ikw) + fl.x, mk;
+        float sy = phm1 + (float)ikh + fl.y, sx = pwm1 + (float)ikw + fl.x, mk;
         if constexpr (ACTIVATED) {
             sy += ry;
             sx += rx;
@@ -239,7 +248,6 @@ __global__ __launch_bounds__(32 * NPF * TPP, (NCF >= 4 ? 32 * NPF * TPP / 256 : 
         const float ay = sy - fy, ax = sx - fx;
         // clamp before the int conversion so wild offsets cannot overflow (one v_med3 each)
         const int y0 = (int)__builtin_amdgcn_fmed3f(fy, -2.f, fH), x0 = (int)__builtin_amdgcn_fmed3f(fx, -2.f, fW);
-        const bool second = cb * BKE >= halfC;                // block-uniform (halfC % BKE == 0)
         const unsigned ld = (unsigned)(second ? a.xLd[1] : a.xLd[0]) * ESZ;
         const unsigned coff = (unsigned)(c - (second ? halfC : 0)) * ESZ;
         const __amdgpu_buffer_rsrc_t xr = second ? xr1 : xr0;
@@ -289,7 +297,35 @@ __global__ __launch_bounds__(32 * NPF * TPP, (NCF >= 4 ? 32 * NPF * TPP / 256 : 
     auto blend_and_stage = [&](const Regs& r, int buf) {
         char* base = stile + buf * BUF;
         uint4 outv;
-        if constexpr (sizeof(E) == 2) {
+        if constexpr (sizeof(E) == 2 && DOT2) {
+            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+            const bf16x2_t w01 = __builtin_bit_cast(bf16x2_t, cvt_pk_bf16(r.wt[0], r.wt[1]));
+            const bf16x2_t w23 = __builtin_bit_cast(bf16x2_t, cvt_pk_bf16(r.wt[2], r.wt[3]));
+            unsigned o[4];
+            const unsigned c0[4] = {r.c[0].x, r.c[0].y, r.c[0].z, r.c[0].w}, c1[4] = {r.c[1].x, r.c[1].y, r.c[1].z, r.c[1].w};
+            const unsigned c2[4] = {r.c[2].x, r.c[2].y, r.c[2].z, r.c[2].w}, c3[4] = {r.c[3].x, r.c[3].y, r.c[3].z, r.c[3].w};
+            float lo[4], hi[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                // (even channel of corner a | even channel of corner b), (odd | odd): one v_perm_b32 each
+                const bf16x2_t tlo = __builtin_bit_cast(bf16x2_t, __builtin_amdgcn_perm(c1[d], c0[d], 0x05040100u));
+                const bf16x2_t thi = __builtin_bit_cast(bf16x2_t, __builtin_amdgcn_perm(c1[d], c0[d], 0x07060302u));
+                const bf16x2_t blo = __builtin_bit_cast(bf16x2_t, __builtin_amdgcn_perm(c3[d], c2[d], 0x05040100u));
+                const bf16x2_t bhi = __builtin_bit_cast(bf16x2_t, __builtin_amdgcn_perm(c3[d], c2[d], 0x07060302u));
+                lo[d] = __builtin_amdgcn_fdot2_f32_bf16(tlo, w01, 0.f, false);
+                hi[d] = __builtin_amdgcn_fdot2_f32_bf16(thi, w01, 0.f, false);
+                lo[d] = __builtin_amdgcn_fdot2_f32_bf16(blo, w23, lo[d], false);
+                hi[d] = __builtin_amdgcn_fdot2_f32_bf16(bhi, w23, hi[d], false);
+            }
+            // HAZARD (gfx950, ROCm 7.2): a vector instruction other than another v_dot2c on the same accumulator that reads a
+            // v_dot2c_f32_bf16 result within 3 wait states gets the OLD register value -- the hardware does not interlock and
+            // hipcc inserts nothing (tools/probes/dot2_hazard.hip).  All eight sums pass through one statement that ends the
+            // last dot and carries the wait states; the conversions below cannot be scheduled above it.
+            asm volatile("s_nop 2" : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]));
+#pragma unroll
+            for (int d = 0; d < 4; ++d) o[d] = cvt_pk_bf16(lo[d], hi[d]);
+            outv = make_uint4(o[0], o[1], o[2], o[3]);
+        } else if constexpr (sizeof(E) == 2) {
             // even / odd channels of each bf16 pair accumulate separately, so the result packs with one
             // v_cvt_pk_bf16_f32 per dword (no re-interleaving)
             // (two-wide vectors: v_pk_fma_f32, one instruction per two channels)
@@ -495,8 +531,8 @@ __global__ __launch_bounds__(32 * NPF * TPP, (NCF >= 4 ? 32 * NPF * TPP / 256 : 
 
 }  // namespace
 
-template <typename E, int NCF, int NPF, int TPP, bool ACTIVATED, bool ONEFRAME>
-static int launch_dcn_v(const DcnArgs& a0, hipStream_t stream) {
+template <typename E, int NCF, int NPF, int TPP, bool ACTIVATED, bool ONEFRAME, bool DOT2>
+static int launch_dcn_v2(const DcnArgs& a0, hipStream_t stream) {
     constexpr int PFD = NCF >= 4 ? 3 : 2;
     DcnArgs a = a0;
     if (ONEFRAME) {      // resources cover one frame: rows outside the image fall outside the resource
@@ -509,12 +545,22 @@ static int launch_dcn_v(const DcnArgs& a0, hipStream_t stream) {
     const size_t lds = (size_t)2 * TP * rawPitch + 2 * (TC + TP) * TPP * 16;
     static LdsAttrOnce attr;
     {
-        const hipError_t e = flair_max_lds_once(attr, reinterpret_cast<const void*>(&dcn_kernel<E, NCF, NPF, TPP, ACTIVATED, ONEFRAME, PFD>));
+        const hipError_t e = flair_max_lds_once(attr, reinterpret_cast<const void*>(&dcn_kernel<E, NCF, NPF, TPP, ACTIVATED, ONEFRAME, PFD, DOT2>));
         FLAIR_CHECK(e == hipSuccess, "flair_dcn_align: hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
-    hipLaunchKernelGGL((dcn_kernel<E, NCF, NPF, TPP, ACTIVATED, ONEFRAME, PFD>), dim3(cdiv(a.P, TP)), dim3(NT), lds, stream, a);
+    hipLaunchKernelGGL((dcn_kernel<E, NCF, NPF, TPP, ACTIVATED, ONEFRAME, PFD, DOT2>), dim3(cdiv(a.P, TP)), dim3(NT), lds, stream, a);
     FLAIR_LAUNCH_CHECK();
     return FLAIR_OK;
+}
+
+// FLAIR_DCN_DOT2 = 0: the f32 blend for bf16 tensors too (A/B switch; the per-frame activated form of the recurrence only)
+template <typename E, int NCF, int NPF, int TPP, bool ACTIVATED, bool ONEFRAME>
+static int launch_dcn_v(const DcnArgs& a, hipStream_t stream) {
+    if constexpr (sizeof(E) == 2 && ACTIVATED && ONEFRAME) {
+        static const bool dot2 = !(getenv("FLAIR_DCN_DOT2") && atoi(getenv("FLAIR_DCN_DOT2")) == 0);
+        if (dot2) return launch_dcn_v2<E, NCF, NPF, TPP, ACTIVATED, ONEFRAME, true>(a, stream);
+    }
+    return launch_dcn_v2<E, NCF, NPF, TPP, ACTIVATED, ONEFRAME, false>(a, stream);
 }
 
 template <typename E, int NCF, int NPF, int TPP>
