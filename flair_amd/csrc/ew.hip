@@ -216,6 +216,61 @@ __global__ void cast_channels_kernel(const float* src, int sLd, int C, long P, E
     }
 }
 
+// y = act(x0 + x1) on [P] pixels of C channels (x1 may be null: y = act(x0)).  The residual sum of a torchvision Bottleneck
+// (`out += identity; out = relu(out)`: the conv epilogues add residuals AFTER the activation) and FPN's lateral sums.
+template <typename E>
+__global__ void add_act_kernel(const E* x0, int ld0, const E* x1, int ld1, int C, long P, int act, E* y, int yLd) {
+    constexpr int VEC = ET<E>::VEC;
+    const int cv = C / VEC;
+    const long total = P * cv;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % cv) * VEC;
+        const long p = i / cv;
+        float a[VEC], b[VEC];
+        Vec16<E>::load(x0 + p * ld0 + c0, a);
+        if (x1) {
+            Vec16<E>::load(x1 + p * ld1 + c0, b);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) a[k] += b[k];
+        }
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) a[k] = apply_act(a[k], act);
+        Vec16<E>::store(y + p * yLd + c0, a);
+    }
+}
+
+// nn.MaxPool2d(kernel_size=3, stride=2, padding=1) on [F][H][W][C] (torchvision ResNet stem): out (H + 1) / 2 x (W + 1) / 2,
+// padding positions do not take part (-inf)
+template <typename E>
+__global__ void maxpool3s2_kernel(const E* x, int xLd, int F, int H, int W, int C, E* y, int yLd) {
+    constexpr int VEC = ET<E>::VEC;
+    const int cv = C / VEC, Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const long total = (long)F * Ho * Wo * cv;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % cv) * VEC;
+        long q = i / cv;
+        const int wo = (int)(q % Wo);
+        q /= Wo;
+        const int ho = (int)(q % Ho), f = (int)(q / Ho);
+        float m[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) m[k] = -INFINITY;
+        for (int dh = -1; dh <= 1; ++dh) {
+            const int h = 2 * ho + dh;
+            if ((unsigned)h >= (unsigned)H) continue;
+            for (int dw = -1; dw <= 1; ++dw) {
+                const int w = 2 * wo + dw;
+                if ((unsigned)w >= (unsigned)W) continue;
+                float v[VEC];
+                Vec16<E>::load(x + (((long)f * H + h) * W + w) * xLd + c0, v);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) m[k] = fmaxf(m[k], v[k]);
+            }
+        }
+        Vec16<E>::store(y + (((long)f * Ho + ho) * Wo + wo) * yLd + c0, m);
+    }
+}
+
 inline int grid_for(long n, int block = 256, int cap = 2048) {
     long g = (n + block - 1) / block;
     if (g > cap) g = cap;
@@ -423,6 +478,41 @@ extern "C" int flair_gated_blend(const void* x, int x_ld, const void* m, int m_l
     } else {
         FLAIR_CHECK(false, "flair_gated_blend: bad dtype");
     }
+    FLAIR_LAUNCH_CHECK();
+    return FLAIR_OK;
+}
+
+extern "C" int flair_add_act_nhwc(const void* x0, int x0_ld, const void* x1, int x1_ld, int dtype, int C, long P, int act, void* y,
+                                  int y_ld, hipStream_t stream) {
+    FLAIR_CHECK(x0 && y && C > 0 && P > 0 && x0_ld >= C && y_ld >= C && (!x1 || x1_ld >= C), "flair_add_act_nhwc: bad argument");
+    FLAIR_CHECK(act >= FLAIR_ACT_NONE && act <= FLAIR_ACT_GELU && act != FLAIR_ACT_DCN_OFFSETS, "flair_add_act_nhwc: activation %d", act);
+    const int vec = dtype == FLAIR_BF16 ? 8 : 4, esz = dtype == FLAIR_BF16 ? 2 : 4;
+    FLAIR_CHECK(dtype == FLAIR_BF16 || dtype == FLAIR_F32, "flair_add_act_nhwc: bad dtype");
+    FLAIR_CHECK(C % vec == 0 && (x0_ld * esz) % 16 == 0 && (y_ld * esz) % 16 == 0 && (!x1 || (x1_ld * esz) % 16 == 0) &&
+                    ((uintptr_t)x0) % 16 == 0 && ((uintptr_t)y) % 16 == 0 && ((uintptr_t)x1) % 16 == 0,
+                "flair_add_act_nhwc: C %% %d, 16-byte aligned rows", vec);
+    if (dtype == FLAIR_BF16)
+        hipLaunchKernelGGL(add_act_kernel<bf16_t>, dim3(grid_for(P * (C / 8))), dim3(256), 0, stream, (const bf16_t*)x0, x0_ld,
+                           (const bf16_t*)x1, x1_ld, C, P, act, (bf16_t*)y, y_ld);
+    else
+        hipLaunchKernelGGL(add_act_kernel<float>, dim3(grid_for(P * (C / 4))), dim3(256), 0, stream, (const float*)x0, x0_ld,
+                           (const float*)x1, x1_ld, C, P, act, (float*)y, y_ld);
+    FLAIR_LAUNCH_CHECK();
+    return FLAIR_OK;
+}
+
+extern "C" int flair_maxpool3x3s2_nhwc(const void* x, int x_ld, int dtype, int F, int H, int W, int C, void* y, int y_ld,
+                                       hipStream_t stream) {
+    FLAIR_CHECK(x && y && F > 0 && H > 0 && W > 0 && C > 0 && x_ld >= C && y_ld >= C, "flair_maxpool3x3s2_nhwc: bad argument");
+    FLAIR_CHECK(dtype == FLAIR_BF16 || dtype == FLAIR_F32, "flair_maxpool3x3s2_nhwc: bad dtype");
+    const int vec = dtype == FLAIR_BF16 ? 8 : 4, esz = dtype == FLAIR_BF16 ? 2 : 4;
+    FLAIR_CHECK(C % vec == 0 && (x_ld * esz) % 16 == 0 && (y_ld * esz) % 16 == 0 && ((uintptr_t)x) % 16 == 0 && ((uintptr_t)y) % 16 == 0,
+                "flair_maxpool3x3s2_nhwc: C %% %d, 16-byte aligned rows", vec);
+    const long n = (long)F * ((H + 1) / 2) * ((W + 1) / 2) * (C / vec);
+    if (dtype == FLAIR_BF16)
+        hipLaunchKernelGGL(maxpool3s2_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, stream, (const bf16_t*)x, x_ld, F, H, W, C, (bf16_t*)y, y_ld);
+    else
+        hipLaunchKernelGGL(maxpool3s2_kernel<float>, dim3(grid_for(n)), dim3(256), 0, stream, (const float*)x, x_ld, F, H, W, C, (float*)y, y_ld);
     FLAIR_LAUNCH_CHECK();
     return FLAIR_OK;
 }

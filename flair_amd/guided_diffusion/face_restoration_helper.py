@@ -45,22 +45,91 @@ class FaceRestoreHelper(object):
     """``FaceRestoreHelper(face_size=512, device=..., face_parse=ParseNet)``: the crop / paste half of the reference class."""
 
     def __init__(self, face_size=512, crop_ratio=(1, 1), det_model="retinaface_resnet50", save_ext="png",
-                 template_3points=False, device=None, face_parse=None, detector=None):
+                 template_3points=False, device=None, face_parse=None, detector=None, face_det=None):
         assert crop_ratio[0] >= 1 and crop_ratio[1] >= 1, "crop ration only supports >=1"
         self.face_size = (int(face_size * crop_ratio[1]), int(face_size * crop_ratio[0]))    # (w, h), as the reference
         self.device = torch.device(device if device is not None else "cuda")
         self.face_parse = face_parse          # flair_amd.guided_diffusion.parsenet.ParseNet (needed by inverse_faces)
-        self.detector = detector
+        self.detector = detector              # optional external object with a get_crop_face method (e.g. the reference's helper)
+        self.face_det = face_det              # flair_amd.guided_diffusion.retinaface.RetinaFace (built on first use when None)
+        self.det_model = det_model
+        self.template_3points = template_3points
+        self.crop_ratio = crop_ratio
+        if template_3points:
+            self.face_template = np.array([[192, 240], [319, 240], [257, 371]], dtype=np.float64)
+        else:                                 # standard 5 landmarks for FFHQ faces with 512 x 512 (face_restoration_helper.py:90-98)
+            self.face_template = np.array([[192.98138, 239.94708], [318.90277, 240.1936], [256.63416, 314.01935],
+                                           [201.26117, 371.41043], [313.08905, 371.15118]])
+        self.face_template = self.face_template * (face_size / 512.0)
+        if crop_ratio[0] > 1:
+            self.face_template[:, 1] += face_size * (crop_ratio[0] - 1) / 2
+        if crop_ratio[1] > 1:
+            self.face_template[:, 0] += face_size * (crop_ratio[1] - 1) / 2
         self._const = {}
         self._minv_cache = {}
 
-    # -- detection half (not built: RetinaFace weights are a network download, alignment is cv2 glue)
-    def get_crop_face(self, *args, **kwargs):
+    # -- detection half (facelib/utils/face_restoration_helper.py:122-224): RetinaFace on the HIP kernels, landmark alignment on
+    # the host (five points per face), the crop itself by flair_warp_affine_cubic
+    def _detector(self):
+        if self.face_det is None:
+            if "retinaface" not in self.det_model:
+                raise NotImplementedError(f"flair_amd: det_model={self.det_model!r} is not built (retinaface_resnet50 only)")
+            from .retinaface import RetinaFace
+            # random initialisation: load detection_Resnet50_Final.pth with face_det.load_state_dict(torch.load(path,
+            # weights_only=True)) -- the reference downloads it at construction (facelib/detection/__init__.py:25-48)
+            self.face_det = RetinaFace(network_name=self.det_model.split("_", 1)[1], half=False, device=self.device)
+        return self.face_det
+
+    def get_crop_face(self, bathed_imgs, only_keep_largest=False, only_center_face=False, resize=None, eye_dist_threshold=None,
+                      face_template_resize=None, face_template_x_offset=None, face_template_y_offset=None):
+        """(B, 3, H, W) frames in [-1, 1] -> (cropped faces (n, 3, face_h, face_w) in [-1, 1], affine matrices, indices of the
+        frames with a face) or (None, None, None).  Detection runs on clamp((x + 1) / 2, 0, 1) * 255 like the reference."""
         if self.detector is not None:
-            return self.detector.get_crop_face(*args, **kwargs)
-        raise NotImplementedError("flair_amd: face detection / landmark alignment (RetinaFace, "
-                                  "face_restoration_helper.py:120-223) is not part of this package; pass the affine "
-                                  "matrices in, or construct the helper with detector=<the reference's FaceRestoreHelper>")
+            return self.detector.get_crop_face(bathed_imgs, only_keep_largest, only_center_face, resize, eye_dist_threshold,
+                                               face_template_resize, face_template_x_offset, face_template_y_offset)
+        from .retinaface_utils import estimate_affine_partial, get_center_face, get_largest_face
+        face_template_resize = 1.0 if face_template_resize is None else face_template_resize
+        face_template_x_offset = 0.0 if face_template_x_offset is None else face_template_x_offset
+        face_template_y_offset = 0.0 if face_template_y_offset is None else face_template_y_offset
+        if resize is not None:
+            raise NotImplementedError("flair_amd: get_crop_face(resize=...) is not built (the reference multiplies a Python list "
+                                      "by the float scale there, face_restoration_helper.py:152, which raises)")
+        x = bathed_imgs.float().contiguous().to(self.device)
+        B, _, H, W = x.shape
+        # VF.normalize(x, [-1] * 3, [2] * 3).clamp(0, 1) * 255 = clamp(127.5 x + 127.5, 0, 255): folded into the detector's
+        # mean-subtraction launch (`pre`)
+        dets = self._detector().batched_detect_faces(x, 0.5, pre=(127.5, 127.5, 0.0, 255.0))
+        # the reference zips the per-frame results with the frames, so a frame WITHOUT detections shifts the pairing
+        # (retinaface.py:393-395 skips it); mirrored: results pair with frames in order
+        affine_matrices, find_face_idx = [], []
+        template = np.stack([self.face_template[:, 0] + face_template_x_offset,
+                             self.face_template[:, 1] + face_template_y_offset], axis=1) * face_template_resize
+        for idx, bboxes in enumerate(dets):
+            landmarks, det_faces = [], []
+            for bbox in bboxes:
+                eye_dist = np.linalg.norm([bbox[5] - bbox[7], bbox[6] - bbox[8]])
+                if eye_dist_threshold is not None and eye_dist < eye_dist_threshold:
+                    continue
+                n = 11 if self.template_3points else 15
+                landmarks.append(np.array([[bbox[i], bbox[i + 1]] for i in range(5, n, 2)]))
+                det_faces.append(bbox[0:5])
+            if len(det_faces) == 0:
+                continue
+            if only_keep_largest:
+                _, k = get_largest_face(det_faces, H, W)
+                landmark = landmarks[k]
+            elif only_center_face:
+                _, k = get_center_face(det_faces, H, W)
+                landmark = landmarks[k]
+            else:
+                landmark = landmarks[0]
+            M = estimate_affine_partial(landmark, template)        # cv2.estimateAffinePartial2D(..., method=cv2.LMEDS)[0]
+            affine_matrices.append(M)
+            find_face_idx.append(idx)
+        if len(affine_matrices) == 0:
+            return None, None, None
+        cropped = self.get_crop_face_from_affine_matrices(x[find_face_idx].contiguous(), affine_matrices)
+        return cropped, affine_matrices, find_face_idx
 
     def _consts(self, dev):
         c = self._const.get(dev)

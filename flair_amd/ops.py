@@ -691,6 +691,26 @@ def vsrpp_warp2(prop, feat2, flow1, flow2, cond1, cond2):
                   launch, ("warp2", H, W, C, second))
 
 
+def add_act(x0, x1=None, act=ACT_NONE, out=None):
+    """act(x0 + x1) on clip tensors (x1 may be None)."""
+    T, H, W, C = x0.shape
+    if out is None:
+        out = torch.empty((T, H, W, C), dtype=x0.dtype, device=x0.device)
+    check(lib().flair_add_act_nhwc(ptr(x0), _ld(x0), ptr(x1), _ld(x1) if x1 is not None else 0, dtype_code(x0), C,
+                                   ctypes.c_long(T * H * W), act, ptr(out), _ld(out), stream()), "flair_add_act_nhwc")
+    return out
+
+
+def maxpool3x3s2(x, out=None):
+    """nn.MaxPool2d(3, 2, 1) on a clip tensor."""
+    T, H, W, C = x.shape
+    if out is None:
+        out = torch.empty((T, (H + 1) // 2, (W + 1) // 2, C), dtype=x.dtype, device=x.device)
+    check(lib().flair_maxpool3x3s2_nhwc(ptr(x), _ld(x), dtype_code(x), T, H, W, C, ptr(out), _ld(out), stream()),
+          "flair_maxpool3x3s2_nhwc")
+    return out
+
+
 def gated_blend(x, m, gate, out=None):
     """x + sigmoid(gate[f, c]) * (m - x); gate: (F, >=C) f32 logits."""
     T, H, W, C = x.shape

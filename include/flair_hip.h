@@ -244,6 +244,14 @@ int flair_affine_channels_f32(const float* x, int x_ld, int C, long P, float a, 
  * (sr3.py:203-226).  x, m, y: [F][HW] pixels of C channels; gate: [F][gate_ld] f32 logits. */
 int flair_gated_blend(const void* x, int x_ld, const void* m, int m_ld, const float* gate, int gate_ld,
                       int dtype, int C, int F, long HW, void* y, int y_ld, hipStream_t stream);
+/* y = act(x0 + x1) on P pixels of C channels (x1 may be NULL): the residual sum of the RetinaFace detector's ResNet-50
+ * Bottleneck (`out += identity; out = relu(out)`: torchvision resnet.py as built by
+ * facelib/detection/retinaface/retinaface.py:99-102) and FPN's lateral sums (retinaface_net.py:88-94). */
+int flair_add_act_nhwc(const void* x0, int x0_ld, const void* x1, int x1_ld, int dtype, int C, long P,
+                       int act, void* y, int y_ld, hipStream_t stream);
+/* nn.MaxPool2d(3, stride 2, padding 1) on [F][H][W][C] -> [F][(H+1)/2][(W+1)/2][C] (the stem of that ResNet-50). */
+int flair_maxpool3x3s2_nhwc(const void* x, int x_ld, int dtype, int F, int H, int W, int C, void* y,
+                            int y_ld, hipStream_t stream);
 /* x[f][p][c] += bias[f][c]  (AttentionbottleBlock h + emb_out, unet_new.py:426-428). */
 int flair_add_frame_bias(void* x, int dtype, int ld, int C, int F, long HW, const float* bias,
                          int bias_ld, hipStream_t stream);

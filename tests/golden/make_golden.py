@@ -216,7 +216,69 @@ def g10_parsenet():
          param_names=np.array(list(sd.keys())), param_shapes=np.array([";".join(map(str, v.shape)) for v in sd.values()]))
 
 
-EXTRA = {"g4": g4_blocks, "g8": g8_blur_forward, "g5_64": g5_unet_64, "g9": g9_codeformer, "g10": g10_parsenet}
+def _load_ref_file(modname, *relpath):
+    import importlib.util
+    import refimport
+    path = os.path.join(refimport.REFERENCE_ROOT, "guided_diffusion", *relpath)
+    spec = importlib.util.spec_from_file_location(modname, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def retinaface_feats(seed=11, hw=(128, 160)):
+    """Stand-ins for the ResNet-50 body's layer2 / layer3 / layer4 outputs of a 128 x 160 image (strides 8 / 16 / 32),
+    fp16-exact so that the fixture can store them as halves."""
+    g = torch.Generator().manual_seed(seed)
+    H, W = hw
+    return [torch.randn(1, c, -(-H // s), -(-W // s), generator=g).half().float() for c, s in ((512, 8), (1024, 16), (2048, 32))]
+
+
+def g11_retinaface():
+    """G11 (detection half): the reference's own FPN / SSH / heads (retinaface_net.py, imports torch only) wired
+    as RetinaFace.__init__ / forward wire them (retinaface.py:104-156, cfg_re50: in_channel 256, out_channel 256, anchors 2),
+    name-seeded weights and BatchNorm statistics under the names the full model gives them, eval mode; plus PriorBox / decode /
+    decode_landm of retinaface_utils.py on the result.  (retinaface.py itself needs cv2 and torchvision's resnet50: the body is
+    not part of this fixture.)"""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    net = _load_ref_file("ref_retinaface_net", "facelib", "detection", "retinaface", "retinaface_net.py")
+    utl = _load_ref_file("ref_retinaface_utils", "facelib", "detection", "retinaface", "retinaface_utils.py")
+
+    class Neck(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fpn = net.FPN([512, 1024, 2048], 256)
+            self.ssh1, self.ssh2, self.ssh3 = net.SSH(256, 256), net.SSH(256, 256), net.SSH(256, 256)
+            self.ClassHead = net.make_class_head(fpn_num=3, inchannels=256)
+            self.BboxHead = net.make_bbox_head(fpn_num=3, inchannels=256)
+            self.LandmarkHead = net.make_landmark_head(fpn_num=3, inchannels=256)
+
+        def forward(self, out):
+            fpn = self.fpn(out)
+            features = [self.ssh1(fpn[0]), self.ssh2(fpn[1]), self.ssh3(fpn[2])]
+            bbox = torch.cat([self.BboxHead[i](f) for i, f in enumerate(features)], dim=1)
+            cls = torch.cat([self.ClassHead[i](f) for i, f in enumerate(features)], dim=1)
+            ldm = torch.cat([self.LandmarkHead[i](f) for i, f in enumerate(features)], dim=1)
+            return bbox, F.softmax(cls, dim=-1), ldm
+    m = Neck()
+    name_seeded_weights(m)
+    m.eval()
+    feats = retinaface_feats()
+    bbox, conf, ldm = m(feats)
+    cfg = {"min_sizes": [[16, 32], [64, 128], [256, 512]], "steps": [8, 16, 32], "variance": [0.1, 0.2], "clip": False}
+    priors = utl.PriorBox(cfg, image_size=(128, 160)).forward()
+    boxes = utl.decode(bbox[0].clone(), priors, cfg["variance"])
+    lms = utl.decode_landm(ldm[0].clone(), priors, cfg["variance"])
+    bb = utl.batched_decode(bbox.clone(), priors.unsqueeze(0), cfg["variance"])
+    sd = m.state_dict()
+    save("g11_retinaface", feat0=feats[0].half(), feat1=feats[1].half(), feat2=feats[2].half(), bbox=bbox, conf=conf, ldm=ldm,
+         priors=priors, boxes=boxes, landmarks=lms, batched_boxes=bb,
+         param_names=np.array(list(sd.keys())), param_shapes=np.array([";".join(map(str, v.shape)) for v in sd.values()]))
+
+
+EXTRA = {"g4": g4_blocks, "g8": g8_blur_forward, "g5_64": g5_unet_64, "g9": g9_codeformer, "g10": g10_parsenet,
+         "g11": g11_retinaface}
 
 
 def main():
