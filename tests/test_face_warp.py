@@ -52,12 +52,18 @@ def test_oracle_blur_matches_scipy():
     assert abs(k.sum() - 1) < 1e-15 and np.array_equal(k, k[::-1])
 
 
-def test_helper_refuses_detection_and_cpu_tensors():
+def test_helper_refuses_unbuilt_detectors_and_cpu_tensors():
+    from flair_amd._lib import FlairHipError
     from flair_amd.guided_diffusion.face_restoration_helper import FaceRestoreHelper, invert_affine
     from oracle import facewarp as fw
+    h = FaceRestoreHelper(device="cpu", det_model="YOLOv5l")
+    with pytest.raises(NotImplementedError):              # only retinaface_resnet50 is built
+        h.get_crop_face(torch.zeros(1, 3, 64, 64))
     h = FaceRestoreHelper(device="cpu")
-    with pytest.raises(NotImplementedError):
-        h.get_crop_face([], None)
+    with pytest.raises(NotImplementedError):              # resize=...: the reference's own expression raises there
+        h.get_crop_face(torch.zeros(1, 3, 64, 64), resize=32)
+    with pytest.raises(FlairHipError):                    # the detector has no CPU path
+        h.get_crop_face(torch.zeros(1, 3, 64, 64))
     assert h.get_crop_face_from_affine_matrices(torch.zeros(0, 3, 8, 8), []) is None
     M = _similarity(1.7, -0.2, 3.0, 9.0)
     assert np.array_equal(invert_affine(M), fw.invert_affine(M))     # host glue == oracle restatement
