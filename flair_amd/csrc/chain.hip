@@ -492,6 +492,7 @@ struct ResArgs {
     float outScale;
     void* y; int yLd;
     int T, H, W;
+    unsigned long long* stamps;   // diagnostic build, debug == 20: per-workgroup sums of s_memtime deltas (wait, barrier, compute, total)
     int debug;            // phase switches of the diagnostic build (-DFLAIR_TIMING_SWITCHES): 1 no MFMA phase, 2 no weight DMA after
                           // the prologue, 3 no epilogue, 4 return after the prologue
 };
@@ -570,6 +571,12 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_resident_kernel(ResArgs 
             const int id = (wave * NWS + i) % WINSTR;
             dma16(wdesc, blk * 64 + wco[i] < a.Cout ? base + wlane[i] : FLAIR_OOB, dst + (unsigned)(id * 1024));
         }
+    };
+    auto issue_w_one = [&](int s_, int i) {                         // instruction i of stage s_ (the stages after the prologue are
+        const int blk = s_ >> 1, ch = s_ & 1;                       // issued one instruction at a time between the taps' MFMAs)
+        const unsigned base = (unsigned)(blk * 64 * 9 * 64) * 2u + (unsigned)(ch * 64);
+        const int id = (wave * NWS + i) % WINSTR;
+        dma16(wdesc, blk * 64 + wco[i] < a.Cout ? base + wlane[i] : FLAIR_OOB, (unsigned)(RING + (s_ % NRING) * SLOT + id * 1024));
     };
     issue_w(0);
     issue_halo(1);
@@ -689,13 +696,18 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_resident_kernel(ResArgs 
     // wait until weight stage s_ (and everything older: halo, biases) has landed for this wave.  Younger operations at this point:
     // the epilogue stores of the two previous stages (NST each once block 1 has started) and the DMA of stage s_ + 1 (NWS).
     auto wait_stage = [&](int s_) {
+        // stage s_ >= 2 was issued DURING stage s_ - 2, its last instruction behind that stage's output stores; younger at this
+        // point: the stores and the DMA instructions of stage s_ - 1
         if (s_ + 1 >= nS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (s_ == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NH + NWS) : "memory");       // halo chunk 1 and stage 1 stay in flight
         else if (s_ <= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWS) : "memory");
-        else if (s_ == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWS + NST) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWS + 2 * NST) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWS + NST) : "memory");
     };
 
+#ifdef FLAIR_TIMING_SWITCHES
+    unsigned long long stW = 0, stB = 0, stC = 0, stT0 = 0;
+    const unsigned long long stStart = __builtin_amdgcn_s_memtime();
+#endif
     f32x16 acc0[RPW][2], acc1[RPW][2];
     // one block = two stages; `accP` accumulates block blk, the epilogue of `accQ` (block blk - 1) runs beside it
     auto block = [&](int blk, f32x16 (&accP)[RPW][2], f32x16 (&accQ)[RPW][2]) {
@@ -703,12 +715,37 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_resident_kernel(ResArgs 
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
             const int s_ = 2 * blk + ch;
+#ifdef FLAIR_TIMING_SWITCHES
+            unsigned long long tA = 0, tB = 0, tC = 0;
+            if (a.debug == 20) tA = __builtin_amdgcn_s_memtime();
+#endif
             wait_stage(s_);
+#ifdef FLAIR_TIMING_SWITCHES
+            if (a.debug == 20) tB = __builtin_amdgcn_s_memtime();
+#endif
             __builtin_amdgcn_s_barrier();            // stage s_ is in LDS for everybody; everybody is done with stage s_ - 1
-            if (s_ + 2 < nS && RES_DBG(a) != 2) issue_w(s_ + 2);        // ring slot (s_ + 2) % 3 = (s_ - 1) % 3 is free
+#ifdef FLAIR_TIMING_SWITCHES
+            if (a.debug == 20) {
+                tC = __builtin_amdgcn_s_memtime();
+                stW += tB - tA;
+                stB += tC - tB;
+                stT0 = tC;
+            }
+#endif
+            const bool dma = s_ + 2 < nS && RES_DBG(a) != 2;          // ring slot (s_ + 2) % 3 = (s_ - 1) % 3 is free from here on
             if (RES_DBG(a) == 4) return;
             if (ch == 0) init_acc(accP, blk);        // (the biases landed with the first stage)
             if (RES_DBG(a) == 1) continue;
+            // the DMA instructions of stage s_ + 2 go out one per step, the last one BEHIND the stage's output stores (wait_stage
+            // counts on that order); issued in one batch ahead of the MFMAs they cost ~100 cycles each with nothing beside them
+            auto dma_step = [&](int step) {
+                if constexpr (RPW == 1) {
+                    constexpr int at[9] = {-1, -1, 0, 1, 2, -1, 3, 4, -1};
+                    if (dma && at[step] >= 0) issue_w_one(s_ + 2, at[step]);
+                } else {
+                    if (dma) issue_w_one(s_ + 2, step);              // NWS == 9
+                }
+            };
             if (prev && RES_DBG(a) != 3) {
                 compute(s_ % NRING, ch, accP, [&](int step) {
                     // 4 RPW pieces per block, 2 RPW per stage, spread over the nine steps
@@ -718,16 +755,30 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_resident_kernel(ResArgs 
                     } else {
                         if (step == 0 || step == 2 || step == 4 || step == 6) epi_piece(accQ, blk - 1, 4 * ch + step / 2);
                     }
+                    dma_step(step);
                 });
             } else {
-                compute(s_ % NRING, ch, accP, [](int) {});
+                compute(s_ % NRING, ch, accP, [&](int step) { dma_step(step); });
             }
+#ifdef FLAIR_TIMING_SWITCHES
+            if (a.debug == 20) {
+                __builtin_amdgcn_sched_barrier(0);
+                stC += __builtin_amdgcn_s_memtime() - stT0;
+            }
+#endif
         }
     };
     for (int blk = 0; blk < nBlk; blk += 2) {
         block(blk, acc0, acc1);
         if (blk + 1 < nBlk) block(blk + 1, acc1, acc0);
     }
+#ifdef FLAIR_TIMING_SWITCHES
+    if (a.debug == 20 && a.stamps && lane == 0) {
+        const unsigned long long tE = __builtin_amdgcn_s_memtime();
+        unsigned long long* d = a.stamps + ((size_t)blockIdx.x * NW + wave) * 4;
+        d[0] = stW; d[1] = stB; d[2] = stC; d[3] = tE - stStart;
+    }
+#endif
     // the last block's epilogue is exposed
     if (RES_DBG(a) == 3) {
 #pragma unroll
@@ -752,8 +803,10 @@ int launch_resident(const ChainArgs& c, hipStream_t s) {
     a.actParam = c.actParam; a.actPeriod = c.actPeriod; a.outScale = c.outScale;
     a.y = c.y; a.yLd = c.yLd; a.T = c.T; a.H = c.H; a.W = c.W;
     a.debug = 0;
+    a.stamps = nullptr;
 #ifdef FLAIR_TIMING_SWITCHES
     a.debug = getenv("FLAIR_RES_DEBUG") ? atoi(getenv("FLAIR_RES_DEBUG")) : 0;
+    if (const char* e = getenv("FLAIR_RES_STAMPS")) a.stamps = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 16));
 #endif
     constexpr size_t lds = 2 * 22 * 1024 + 3 * 36 * 1024 + 2048;
     const int grid = a.T * (a.H / 8) * (a.W / 32);
