@@ -112,6 +112,18 @@ __device__ __forceinline__ void dcn_offset_act(float (&v)[N], int co, float mag,
     }
 }
 
+// The same activation with per-lane constants (the N consecutive channels of a call share their class): out = A * rcp(1 + 2^(k v)) + B,
+// residues: mag tanh(v) = mag - 2 mag / (1 + e^{2v}); masks: 1 / (1 + e^{-v}) -- three vector and two transcendental instructions
+// per value instead of eight and two; `scale` (the convolution's out_scale) is folded into A and B.
+template <int N>
+__device__ __forceinline__ void dcn_offset_act_fast(float (&v)[N], int co, float mag, int period, float scale) {
+    const bool residue = 3 * (co % period) < 2 * period;
+    const float kk = residue ? 2.885390081777927f : -1.4426950408889634f;       // 2 log2(e) | -log2(e)
+    const float A = residue ? -2.f * mag * scale : scale, B = residue ? mag * scale : 0.f;
+#pragma unroll
+    for (int e = 0; e < N; ++e) v[e] = fmaf(__builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(kk * v[e])), A, B);
+}
+
 // ---- buffer loads: out-of-range offsets return 0, which gives zero padding for free and keeps
 // the loads unconditional (a select or branch on a load result makes hipcc wait vmcnt(0) at once).
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;

@@ -1258,13 +1258,13 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], v[e] * slope);
                     } else if constexpr (ACT == 1) {
-                        dcn_offset_act<8>(v, tl.co0 + cofs + cl, a.actParam, a.actPeriod);
-                    } else {
+                        dcn_offset_act_fast<8>(v, tl.co0 + cofs + cl, a.actParam, a.actPeriod, 1.f);
+                    } else if constexpr (ACT == 2) {
                         // v_rcp_f32 (1 ulp) instead of the IEEE divide of silu_f: ten instructions less per element, and the
                         // result is rounded to bf16 right below
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] *= __builtin_amdgcn_rcpf(1.f + __expf(-v[e]));
-                    }
+                    }                                      // ACT == 3: no activation and out_scale == 1 (the ResBlock convolutions)
                     if constexpr (HASRES) {
                         float r[8];
                         Vec16<E>::load(reinterpret_cast<const E*>(&r0v[i][jj][j]), r);      // zeros without res0 / on padding lanes
@@ -1276,8 +1276,10 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
                             for (int e = 0; e < 8; ++e) v[e] += r[e];
                         }
                     }
+                    if constexpr (ACT != 3) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] *= scale;
+                        for (int e = 0; e < 8; ++e) v[e] *= scale;
+                    }
                     alignas(16) E out[8];
                     Vec16<E>::store(out, v);
                     const uint4 ov = *reinterpret_cast<const uint4*>(out);
@@ -1370,6 +1372,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
         };
         if (a.act == FLAIR_ACT_DCN_OFFSETS) go(std::integral_constant<int, 1>{});
         else if (a.act == FLAIR_ACT_SILU) go(std::integral_constant<int, 2>{});
+        else if (RPW == 2 && a.act == FLAIR_ACT_NONE && a.outScale == 1.f) go(std::integral_constant<int, 3>{});   // pack + store only
         else go(std::integral_constant<int, 0>{});      // NONE / RELU / LeakyReLU (GELU: refused on the host)
     };
     // Residual prefetch: one 4-byte LDS-DMA per output pixel of the wave (64 couts x 2 bytes = the pixel's 128-byte line),

@@ -20,6 +20,14 @@ timeout -k 10 150 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pmc_fetch -o
 timeout -k 10 150 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pmc_write -o b --output-format csv -- python $R/tools/pmc_dominant.py $OUT/bench_full.json > /dev/null 2>&1
 python $R/tools/pmc_traffic.py /tmp/pmc_fetch /tmp/pmc_write $OUT/hbm_traffic_pmc.json > $OUT/hbm_traffic_pmc.txt
 cd $R
+# round 4: HBM traffic of EVERY kernel of the steady-state steps (FLAIR_BENCH_REPLAY=off: nothing but the steps' own launches; 14 s per pass)
+bash tools/pmc_whole_step.sh gpurun_out/$TAG/pmc_whole 300 > /dev/null 2>&1
+cp $OUT/pmc_whole/hbm_traffic_pmc_whole_step.txt $OUT/pmc_whole/hbm_traffic_pmc_whole_step.json $OUT/pmc_whole/passes.log $OUT/ 2>/dev/null
+# the literal 16,32,64 attention layout of SURVEY.md section 3.2 beside the benched one
+timeout -k 10 300 python bench.py --steps 30 --warmup 3 --no-cpu-baseline --attention-resolutions 16,32,64 > $OUT/bench_attn_16_32_64.json 2>/dev/null
+tail -1 $OUT/bench_attn_16_32_64.json | cut -c1-200
+python tools/bench_conv6.py > $OUT/conv6_isolated.txt 2>/dev/null
+bash tools/pmc_dcn.sh gpurun_out/$TAG/dcn_pmc_sq.txt > /dev/null 2>&1
 timeout -k 10 300 python bench.py --task x8_bicubic --no-cpu-baseline > $OUT/bench_x8_bicubic.json 2>/dev/null
 timeout -k 10 300 python bench.py --task jpeg --no-cpu-baseline > $OUT/bench_jpeg.json 2>/dev/null
 tail -1 $OUT/bench_x8_bicubic.json | cut -c1-200
