@@ -533,7 +533,7 @@ __global__ __launch_bounds__(32 * NPF * TPP, (NCF >= 4 ? 32 * NPF * TPP / 256 : 
 
 template <typename E, int NCF, int NPF, int TPP, bool ACTIVATED, bool ONEFRAME, bool DOT2>
 static int launch_dcn_v2(const DcnArgs& a0, hipStream_t stream) {
-    constexpr int PFD = NCF >= 4 ? 3 : 2;
+    constexpr int PFD = NCF >= 4 && TPP <= 8 ? 3 : 2;
     DcnArgs a = a0;
     if (ONEFRAME) {      // resources cover one frame: rows outside the image fall outside the resource
         const unsigned long long half = a.Cin / 2, hw = (unsigned long long)a.H * a.W;
@@ -611,7 +611,12 @@ extern "C" int flair_dcn_align(const flair_dcn_params* p, const void* x0, const 
             // c = 128: every workgroup streams the whole 590 KB weight matrix, so the pixel tile sets the weight traffic
             // (32-pixel tiles: 512 workgroups x 590 KB = 302 MB per 128x128 frame against 151 MB of gathers).
             // FLAIR_DCN_TILE_C128 = 64: 64-pixel tiles (8 waves, one workgroup per CU on a 128x128 frame) halve it.
-            static const int tile128 = getenv("FLAIR_DCN_TILE_C128") ? atoi(getenv("FLAIR_DCN_TILE_C128")) : 32;
+            static const int tile128 = getenv("FLAIR_DCN_TILE_C128") ? atoi(getenv("FLAIR_DCN_TILE_C128")) : 1664;
+            // 1664 (default since round 4): 64-pixel tiles with SIXTEEN threads per pixel -- one K step = 128 channels = one input half
+            // of one tap (18 steps instead of 36), 16 waves per workgroup, one workgroup per CU on a 128x128 frame: twice the waves
+            // in flight per CU, half the barriers, half the weight traffic of the 32-pixel tiles: 43.0 -> 32.7 us per launch
+            // (tools/bench_dcn.py, same box).  32 / 64: the round-2/3 forms.
+            if (tile128 == 1664 && a.P >= 64 * 256 && (p->Cin / 2) % 128 == 0) return launch_dcn<bf16_t, 4, 2, 16>(a, stream);
             if (tile128 >= 64 && a.P >= 64 * 256) return launch_dcn<bf16_t, 4, 2, 8>(a, stream);
             return launch_dcn<bf16_t, 4, 1, 8>(a, stream);
         }

@@ -405,7 +405,7 @@ def test_dcn(dev, dtype, c, hw):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("c,hw", [(64, (32, 32)), (128, (16, 40))])
+@pytest.mark.parametrize("c,hw", [(64, (32, 32)), (128, (16, 40)), (128, (128, 128)), (64, (256, 256))])
 def test_dcn_activated_raw(dev, dtype, c, hw):
     """flair_dcn_align with raw_activated=1: residues / masks arrive finished (the producing convolution's
     FLAIR_ACT_DCN_OFFSETS epilogue), rounded to the element type like any stored activation."""

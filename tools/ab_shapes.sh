@@ -1,13 +1,13 @@
 # Same-box A/B per launch shape: bench.py's roofline leg (every distinct launch shape replayed alone) with the previous and the new library.
 export PYTHONPATH=$PWD
-OUT=${1:-gpurun_out/abs}; mkdir -p $OUT
+OUT=${1:-gpurun_out/abs}; mkdir -p $OUT; export ABS_OUT=$OUT
 for lib in prev new; do
   if [ $lib = prev ]; then export FLAIR_HIP_LIB=$PWD/tools/probes/libflair_prev.so; else unset FLAIR_HIP_LIB; fi
   timeout -k 10 400 python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>>$OUT/err.log | tail -1 > $OUT/$lib.json
 done
 python - <<'PY'
 import json
-a=json.load(open('gpurun_out/abs/prev.json')); b=json.load(open('gpurun_out/abs/new.json'))
+a=json.load(open(''+__import__("os").environ.get("ABS_OUT","gpurun_out/abs")+'/prev.json')); b=json.load(open(''+__import__("os").environ.get("ABS_OUT","gpurun_out/abs")+'/new.json'))
 print('ms/step', a['ms_per_step'], b['ms_per_step'])
 def fam(j):
     out={}
