@@ -1912,7 +1912,12 @@ int dispatch(const ConvArgs& a0, hipStream_t s) {
             static const int rpw2 = getenv("FLAIR_KS_RPW2") ? atoi(getenv("FLAIR_KS_RPW2")) : 0;
             return rpw2 ? launch_halo_ks<E, 8, 2, 2>(a, s) : launch_halo_ks<E, 8, 1, 2>(a, s);
         }
-        case 7: return launch_halo_ks<E, 4, 1, 2>(a, s);   // (two rows per wave leave 4 waves per CU here: +3.5 ms/step)
+        case 7: {
+            // (two rows per wave leave 4 waves per CU here: +3.5 ms/step)
+            // FLAIR_KS_CF1=1: one 32-cout fragment per wave, i.e. 16 waves per workgroup on the 4-row tiles of the 128^2 level
+            static const int cf1 = getenv("FLAIR_KS_CF1") ? atoi(getenv("FLAIR_KS_CF1")) : 0;
+            return cf1 ? launch_halo_ks<E, 4, 1, 1>(a, s) : launch_halo_ks<E, 4, 1, 2>(a, s);
+        }
         case 8: return launch_dma<8, 2, 2>(a, s);
         case 9: return launch_dma<8, 1, 2>(a, s);
         case 10: return launch_dma<4, 1, 3>(a, s);
