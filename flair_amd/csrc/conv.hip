@@ -1217,21 +1217,25 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
         const unsigned yLane = (unsigned)lr * yLdB + 2u * cl, rLane = (unsigned)lr * rLdB + 2u * cl;
         // Without a residual no load is issued at all: a load here is younger than the next chunk's DMA pieces, so waiting
         // for it also waits for those, which otherwise have the whole epilogue left to land (+9 us on a 105 us convolution).
-        uint4 r0v[2][2][RPW];
-        if constexpr (HASRES) {
+        constexpr bool ALLUP = RPW <= 2;           // four rows per wave: one batch per 32-cout fragment (the accumulators leave no room for all 16 pieces)
+        uint4 r0v[ALLUP ? 2 : 1][2][RPW];
+        auto res_request = [&](int i) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int jj = 0; jj < 2; ++jj) {
+                const int cofs = i * 32 + 16 * jj;
+                const bool lane_ok = tl.co0 + cofs + cl < a.Cout;
 #pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
-                    const int cofs = i * 32 + 16 * jj;
-                    const bool lane_ok = tl.co0 + cofs + cl < a.Cout;
-#pragma unroll
-                    for (int j = 0; j < RPW; ++j)
-                        r0v[i][jj][j] = buf_load16(r0d, lane_ok ? rLane + (unsigned)(j * W) * rLdB + 2u * cofs : FLAIR_OOB);
-                }
+                for (int j = 0; j < RPW; ++j)
+                    r0v[ALLUP ? i : 0][jj][j] = buf_load16(r0d, lane_ok ? rLane + (unsigned)(j * W) * rLdB + 2u * cofs : FLAIR_OOB);
+            }
+        };
+        if constexpr (HASRES && ALLUP) {
+            res_request(0);
+            res_request(1);
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i) {
+            if constexpr (HASRES && !ALLUP) res_request(i);
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
                 const int cofs = i * 32 + 16 * jj;                                       // cout offset of this group inside the tile
@@ -1267,7 +1271,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
                     }                                      // ACT == 3: no activation and out_scale == 1 (the ResBlock convolutions)
                     if constexpr (HASRES) {
                         float r[8];
-                        Vec16<E>::load(reinterpret_cast<const E*>(&r0v[i][jj][j]), r);      // zeros without res0 / on padding lanes
+                        Vec16<E>::load(reinterpret_cast<const E*>(&r0v[ALLUP ? i : 0][jj][j]), r);      // zeros without res0 / on padding lanes
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] += r[e];
                         if (r1b && lane_ok) {
@@ -1289,6 +1293,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
                     else asm volatile("" ::"v"(ov.x), "v"(ov.y), "v"(ov.z), "v"(ov.w));
                 }
             }
+        }
     };
     // One-tile forms (RPW == 1, the per-frame launches): the plain epilogue -- global loads / stores under EXEC-masked
     // branches.  The buffer-descriptor form below costs these launches ~0.15 us per K chunk (its descriptors raise the
@@ -1372,7 +1377,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
         };
         if (a.act == FLAIR_ACT_DCN_OFFSETS) go(std::integral_constant<int, 1>{});
         else if (a.act == FLAIR_ACT_SILU) go(std::integral_constant<int, 2>{});
-        else if (RPW == 2 && a.act == FLAIR_ACT_NONE && a.outScale == 1.f) go(std::integral_constant<int, 3>{});   // pack + store only
+        else if (RPW >= 2 && a.act == FLAIR_ACT_NONE && a.outScale == 1.f) go(std::integral_constant<int, 3>{});   // pack + store only
         else go(std::integral_constant<int, 0>{});      // NONE / RELU / LeakyReLU (GELU: refused on the host)
     };
     // Residual prefetch: one 4-byte LDS-DMA per output pixel of the wave (64 couts x 2 bytes = the pixel's 128-byte line),
@@ -1382,13 +1387,16 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
     auto prefetch_res = [&](const DmaTile& tl) {
         const long p0w = ((long)tl.t * H + tl.h0 + RPW * wave) * W + tl.w0;
         const u32x4_t rd = make_desc(reinterpret_cast<const char*>(a.res0) + (p0w * a.res0Ld + tl.co0) * 2, (unsigned)(RPW * W * a.res0Ld) * 2u);
-        const int j = lane >> 5;
-        const unsigned voff = j < RPW ? (unsigned)((j * W + lr) * a.res0Ld) * 2u : FLAIR_OOB;
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep)
-                     : "v"(voff), "s"((unsigned)(NSTAGE * STAGE_BYTES + wave * 1024)), "s"(rd)
-                     : "memory");
+#pragma unroll
+        for (int jj = 0; jj < (RPW + 1) / 2; ++jj) {
+            const int j = 2 * jj + (lane >> 5);
+            const unsigned voff = j < RPW ? (unsigned)((j * W + lr) * a.res0Ld) * 2u : FLAIR_OOB;
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(voff), "s"((unsigned)(NSTAGE * STAGE_BYTES + wave * 1024)), "s"(rd)
+                         : "memory");
+        }
     };
 
     // ---- the (tile, chunk) pipeline.  `cur` is the tile being multiplied, `nxt` the tile whose chunks are being issued.
@@ -1468,7 +1476,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
                 bias_request(nxt);
             }
         }
-        if constexpr (RPW == 2)
+        if constexpr (RPW >= 2)
             if (remCompute == 1 && a.res0 && FLAIR_DBG(a) != 19) prefetch_res(cur);
         if (more) {
             if (FLAIR_DBG(a) != 12) issue(nxt, wk, stage ^ 1);     // (timing switches: 11 no MFMA phase, 12 no DMA, 13 no epilogue)
@@ -1484,7 +1492,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
                 // every tile issues exactly 4 * RPW store instructions per wave as its youngest memory operations (a second
                 // residual is loaded under a branch, where hipcc places its own waits: not counted on)
                 // (RPW == 2: padding lanes' stores are issued too, out of range; RPW == 1: full tiles without a residual branch)
-                storesInFlight = (RPW == 2 ? !a.res1 : cur.co0 + 64 <= a.Cout && !res0any) && FLAIR_DBG(a) != 14 && FLAIR_DBG(a) != 16;
+                storesInFlight = (RPW >= 2 ? !a.res1 : cur.co0 + 64 <= a.Cout && !res0any) && FLAIR_DBG(a) != 14 && FLAIR_DBG(a) != 16;
             }
             ++iCur;
             if (!tile_at(iCur, cur)) break;
@@ -1495,8 +1503,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
         // with the 8 epilogue stores as the youngest operations vmcnt(8) retires every DMA and leaves the stores in flight
         // (waiting for their acknowledgement from memory cost 40 % of a two-chunk convolution: profiles/r03_dma_switches.txt)
         if (storesInFlight) {
-            if constexpr (RPW == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * RPW) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -1918,7 +1925,12 @@ int dispatch(const ConvArgs& a0, hipStream_t s) {
             static const int cf1 = getenv("FLAIR_KS_CF1") ? atoi(getenv("FLAIR_KS_CF1")) : 0;
             return cf1 ? launch_halo_ks<E, 4, 1, 1>(a, s) : launch_halo_ks<E, 4, 1, 2>(a, s);
         }
-        case 8: return launch_dma<8, 2, 2>(a, s);
+        case 8: {
+            // FLAIR_DMA_RPW4=1: four waves of FOUR rows x 32 pixels x 64 couts (eight accumulators per wave, one wave per SIMD):
+            // 72 fragment reads per 144 MFMAs instead of 60 per 72
+            static const int rpw4 = getenv("FLAIR_DMA_RPW4") ? atoi(getenv("FLAIR_DMA_RPW4")) : 0;
+            return rpw4 ? launch_dma<4, 4, 2>(a, s) : launch_dma<8, 2, 2>(a, s);
+        }
         case 9: return launch_dma<8, 1, 2>(a, s);
         case 10: return launch_dma<4, 1, 3>(a, s);
         default: return launch_halo<E, 2, 1, 1>(a, s);
