@@ -47,6 +47,8 @@ struct ConvArgs {
     float outScale;
     long P;  // T*H*W
     int nPixTiles, nCoTiles;
+    int tFast;             // DMA kernel: frame index fastest in the tile order (launches with temporal taps)
+    int resPrefetch;       // DMA kernel: 0 no residual prefetch, 1 LDS-DMA touch of the residual lines one chunk ahead
     unsigned segBytes[4];  // addressable bytes of each input segment / of the weights
     unsigned wBytes;
     float* part;           // split-K: f32 partial sums [splitK][P][Cout] (null when splitK == 1)
@@ -1022,6 +1024,15 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
         int rest = id;
         tl.co0 = (rest % nCoTiles) * 64;
         rest /= nCoTiles;
+        if (a.tFast) {
+            // temporal taps: the frame index runs fastest, so the workgroups of an XCD work on ALL frames of a few spatial tiles at
+            // the same time and the three output frames that read one input tile find it in that XCD's L2 together
+            tl.t = rest % T;
+            rest /= T;
+            tl.w0 = (rest % tilesW) * 32;
+            tl.h0 = (rest / tilesW) * TH;
+            return true;
+        }
         tl.w0 = (rest % tilesW) * 32;
         rest /= tilesW;
         tl.h0 = (rest % tilesH) * TH;
@@ -1064,11 +1075,16 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
     const u32x4_t wdesc = make_desc(a.w, a.wBytes);
     // K walk state of the ISSUE side (block uniform)
     struct Walk {
-        int dt, seg, cb, segOff;
+        int dt, seg, cb, segOff, j;
     };
+    // tFast: the temporal taps are walked in an order rotated by the output frame, dt_j(t) = ((j - t) mod KT) - pt, so that the three
+    // workgroups that read one input tile (output frames t - 1, t, t + 1 of one spatial tile, side by side on one XCD) ask for it at
+    // the same position of their walks instead of two / four chunk times apart
+    auto dt_at = [&](int t, int j) { return a.tFast ? (j + a.KT * T - t) % a.KT - pt : j - pt; };
     auto walk_first = [&](int t, Walk& wk) {
-        wk.dt = -pt; wk.seg = 0; wk.cb = 0; wk.segOff = 0;
-        while (wk.dt <= pt && (unsigned)(t + wk.dt) >= (unsigned)T) ++wk.dt;
+        wk.j = 0; wk.seg = 0; wk.cb = 0; wk.segOff = 0;
+        while (wk.j < a.KT && (unsigned)(t + dt_at(t, wk.j)) >= (unsigned)T) ++wk.j;
+        wk.dt = dt_at(t, wk.j);
     };
     auto walk_next = [&](int t, Walk& wk) {
         ++wk.cb;
@@ -1078,8 +1094,9 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
             if (++wk.seg >= a.nseg) {
                 wk.seg = 0;
                 wk.segOff = 0;
-                ++wk.dt;
-                while (wk.dt <= pt && (unsigned)(t + wk.dt) >= (unsigned)T) ++wk.dt;
+                ++wk.j;
+                while (wk.j < a.KT && (unsigned)(t + dt_at(t, wk.j)) >= (unsigned)T) ++wk.j;
+                wk.dt = dt_at(t, wk.j);        // (past the last tap: never issued, remIssue ends the walk)
             }
         }
     };
@@ -1477,7 +1494,9 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
             }
         }
         if constexpr (RPW >= 2)
-            if (remCompute == 1 && a.res0 && FLAIR_DBG(a) != 19) prefetch_res(cur);
+            if (remCompute == 1 && a.res0 && FLAIR_DBG(a) != 19) {
+                if (a.resPrefetch == 1) prefetch_res(cur);
+            }
         if (more) {
             if (FLAIR_DBG(a) != 12) issue(nxt, wk, stage ^ 1);     // (timing switches: 11 no MFMA phase, 12 no DMA, 13 no epilogue)
             walk_next(nxt.t, wk);
@@ -1517,6 +1536,12 @@ int launch_dma(const ConvArgs& a0, hipStream_t s) {
     constexpr int TH = NW * RPW;
     ConvArgs a = a0;
     a.nCoTiles = cdiv(a.Cout, 64);
+    static const int tfast = getenv("FLAIR_DMA_TFAST") ? atoi(getenv("FLAIR_DMA_TFAST")) : 1;
+    a.tFast = tfast && a.KT == 3 && a.T > 1;
+    // round 4: the touch no longer pays (clip-level family 16.62 / 16.71 ms without, 16.73 / 16.74 with, same box) and the counters show
+    // the touched lines fetched a second time by the real loads (profiles/r04_dma_read_traffic_by_shape.txt): off by default
+    static const int resPf = getenv("FLAIR_DMA_RES_PREFETCH") ? atoi(getenv("FLAIR_DMA_RES_PREFETCH")) : 0;
+    a.resPrefetch = resPf;
     const int nTiles = a.T * (a.H / TH) * (a.W / 32) * a.nCoTiles;
     const int nCu = flair_cu_count();                                  // of the CURRENT device
     int grid = nTiles < nCu ? (nTiles + 7) / 8 * 8 : nCu / 8 * 8;      // a multiple of 8: every XCD gets the same number of slots
