@@ -613,6 +613,46 @@ def main():
                                        "achieved": fl_ / us_ / 1e6, "peak": MFMA_PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
                                        "frac": fl_ / us_ / 1e6 / MFMA_PEAK_TFLOPS["bf16"], "target_frac": 0.50})
             del qkv_, out_
+    # ---- what THIS device sustains with nothing in the way (calibration launches of the library, include/flair_hip.h): independent
+    # bf16 MFMA chains out of registers in a launch of per-frame length (~80 us, replayed back to back like every shape above) and
+    # in one ~7 ms launch; read / write / copy of 1 GiB.  Fractions above stay against the data-sheet peaks; this block says how
+    # much of those peaks the silicon reaches at the clock it holds under load (profiles/r04_attainable_peaks.txt).
+    attainable = None
+    if a.dtype == "bf16":
+        sink_ = torch.zeros(4, dtype=torch.float32, device=dev)
+        fl_short = ops.probe_matrix_rate(250, 1, sink_)
+        us_short = replay_us(lambda: ops.probe_matrix_rate(250, 1, sink_))
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fl_long = ops.probe_matrix_rate(25000, 1, sink_)
+        torch.cuda.synchronize()
+        c0.record()
+        ops.probe_matrix_rate(25000, 1, sink_)
+        c1.record()
+        torch.cuda.synchronize()
+        us_long = c0.elapsed_time(c1) * 1e3
+        buf_a = torch.empty(1 << 30, dtype=torch.uint8, device=dev).fill_(1)
+        buf_b = torch.empty(1 << 30, dtype=torch.uint8, device=dev).fill_(2)
+        stream_rates = {}
+        for name_, mode_ in (("read", 0), ("write", 1), ("copy", 2)):
+            moved_ = ops.probe_stream_rate(buf_a, buf_b, mode_)
+            torch.cuda.synchronize()
+            best_ = None
+            for _ in range(3):
+                c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                c0.record()
+                ops.probe_stream_rate(buf_a, buf_b, mode_)
+                c1.record()
+                torch.cuda.synchronize()
+                t_ = c0.elapsed_time(c1) * 1e3
+                best_ = t_ if best_ is None else min(best_, t_)
+            stream_rates[name_ + "_1GiB_GB/s"] = moved_ / best_ / 1e3
+        del buf_a, buf_b
+        attainable = {"matrix_TFLOP/s_80us_launches": fl_short / us_short / 1e6, "matrix_TFLOP/s_7ms_launch": fl_long / us_long / 1e6,
+                      "matrix_frac_of_peak": [fl_short / us_short / 1e6 / MFMA_PEAK_TFLOPS["bf16"], fl_long / us_long / 1e6 / MFMA_PEAK_TFLOPS["bf16"]],
+                      **stream_rates, "copy_frac_of_peak": stream_rates["copy_1GiB_GB/s"] / HBM_PEAK_GBS,
+                      "note": "measured on this device in this process: v_mfma_f32_32x32x16_bf16 chains out of registers on every CU; "
+                              "16-byte grid-stride streaming kernels; the data-sheet peaks assume 2.4 GHz and 8 TB/s"}
+
     # ---- the whole step against the MFMA peak: every FLOP the instrumented steady-state step issued on the matrix cores
     # (convolutions, fused chains, alignment GEMM + bilinear blends, QK^T / AV) over the timed mean step; SPyNet is not in it
     # (its flows are cached per clip: not executed in a steady-state step), GroupNorm / warps / sampler count as zero FLOPs.
@@ -658,6 +698,7 @@ def main():
                      "whole_step": whole_step,
                      "resblock_path": resblock_path,
                      "attention_isolated": attention_isolated,
+                     "attainable_on_this_device": attainable,
                      "families": fams},
     }
     if rank == 0:

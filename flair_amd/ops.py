@@ -711,6 +711,28 @@ def maxpool3x3s2(x, out=None):
     return out
 
 
+# --------------------------------------------------------------------------- calibration launches (measurement only)
+def probe_matrix_rate(iters, workgroups_per_cu=1, sink=None):
+    """One launch of independent bf16 MFMA chains out of registers on every CU (flair_probe_matrix_rate); returns its FLOPs.
+    The caller times it with events on the current stream."""
+    if sink is None:
+        sink = torch.zeros(4, dtype=torch.float32, device="cuda")
+    flop = ctypes.c_double(0.0)
+    check(lib().flair_probe_matrix_rate(int(iters), int(workgroups_per_cu), ptr(sink), ctypes.byref(flop), stream()),
+          "flair_probe_matrix_rate")
+    return flop.value
+
+
+def probe_stream_rate(src, dst, mode):
+    """mode 0: read src, 1: write dst, 2: copy src -> dst (uint8 / any contiguous device tensors of equal size); returns the bytes moved."""
+    n = dst.numel() * dst.element_size()
+    if mode != 1:
+        assert src.numel() * src.element_size() == n
+    check(lib().flair_probe_stream_rate(ptr(src) if mode != 1 else ctypes.c_void_p(0), ptr(dst), ctypes.c_size_t(n), int(mode), stream()),
+          "flair_probe_stream_rate")
+    return n * (2 if mode == 2 else 1)
+
+
 def gated_blend(x, m, gate, out=None):
     """x + sigmoid(gate[f, c]) * (m - x); gate: (F, >=C) f32 logits."""
     T, H, W, C = x.shape

@@ -59,7 +59,7 @@ typedef enum {
 /* Last error message of the calling thread ("" if none). */
 const char* flair_last_error(void);
 /* ABI version of this header: bumped whenever entry points are added or a struct changes
- * (3: round 2; 4: + face crop / paste entries, flair_bcast_weights; 5: round 4 entries).
+ * (3: round 2; 4: + face crop / paste entries, flair_bcast_weights; 5: round 4 entries; 6: + calibration launches).
  * The library may be used from several devices of one process: per-kernel launch attributes and
  * CU counts are cached per device. */
 int flair_abi_version(void);
@@ -437,6 +437,16 @@ int flair_face_blend(const float* x0, const float* face, const float* mask, int 
  * one broadcast per parameter).  librccl is bound with dlopen at the first call.  Clips are independent after that: no
  * data-path collective exists. */
 int flair_bcast_weights(void* blob, size_t bytes, int root, void* rccl_comm, hipStream_t stream);
+
+/* ------------------------------------------------------------- calibration launches (measurement only)
+ * No counterpart in the reference: they exist so that bench.py can print, beside every roofline fraction against the data-sheet
+ * peaks, what the device it ran on sustains with nothing in the way (profiles/r04_attainable_peaks.txt).
+ * flair_probe_matrix_rate: workgroups_per_cu x CU-count workgroups of four waves, each wave `iters` x 16 independent
+ *   v_mfma_f32_32x32x16_bf16 out of registers; *flop_out (host, optional) = FLOPs of the launch; sink: >= 4 bytes of device memory
+ *   (never written).  flair_probe_stream_rate: mode 0 reads `bytes` from src, 1 writes `bytes` to dst, 2 copies src -> dst
+ *   (16-byte accesses, grid-stride).  The caller times them with events on `stream`. */
+int flair_probe_matrix_rate(int iters, int workgroups_per_cu, float* sink, double* flop_out, hipStream_t stream);
+int flair_probe_stream_rate(const void* src, void* dst, size_t bytes, int mode, hipStream_t stream);
 
 #ifdef __cplusplus
 }

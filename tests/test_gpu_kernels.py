@@ -580,3 +580,20 @@ def test_flash_attn_wrapper_calling_convention(dev, dtype):
     assert_close(got.float().cpu(), ref, dtype, "flash_attn_wrapper")
     with pytest.raises(NotImplementedError):
         fnn.flash_attn_wrapper(q.to(dev), k.to(dev), v.to(dev), 0.1)
+
+
+@pytest.mark.gpu
+def test_calibration_launches():
+    """flair_probe_matrix_rate / flair_probe_stream_rate (measurement-only entries of the C ABI): they run, report their work, the copy copies."""
+    ops = _ops()
+    flop = ops.probe_matrix_rate(10, 1)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert flop == cus * 4 * 10 * 16 * 2.0 * 32 * 32 * 16
+    src = torch.randint(0, 255, (1 << 20,), dtype=torch.uint8, device="cuda")
+    dst = torch.zeros_like(src)
+    assert ops.probe_stream_rate(src, dst, 2) == 2 << 20
+    torch.cuda.synchronize()
+    assert torch.equal(src, dst)
+    assert ops.probe_stream_rate(src, dst, 0) == 1 << 20
+    with pytest.raises(Exception):
+        ops.probe_matrix_rate(0, 1)
