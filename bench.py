@@ -43,7 +43,8 @@ CONV_VARIANTS = {0: "conv_igemm_kernel<128co x 128px>", 1: "conv_igemm_kernel<64
                  2: "conv_igemm_kernel<64co x 64px>", 3: "conv3x3_halo_kernel<8 rows>",
                  4: "conv3x3_halo_kernel<4 rows>", 5: "conv3x3_halo_kernel<2 rows>",
                  6: "conv3x3_halo_ks_kernel<8 rows>", 7: "conv3x3_halo_ks_kernel<4 rows>",
-                 8: "conv3x3_dma_kernel<16 rows, persistent>", 9: "conv3x3_dma_kernel<8 rows>", 10: "conv3x3_dma_kernel<4 rows>"}
+                 8: "conv3x3_dma_kernel<16 rows, persistent>", 9: "conv3x3_dma_kernel<8 rows>", 10: "conv3x3_dma_kernel<4 rows>",
+                 11: "conv3x3_dma_kernel<4 rows, K split>"}
 
 
 def pmc_traffic_for(kernel_fmt, dkey):

@@ -992,11 +992,18 @@ struct DmaTile {
 //   NSTAGE = 3 (one-tile launches only): three LDS stages, chunks n + 1 and n + 2 in flight while chunk n is multiplied (counted
 //   vmcnt): a per-frame launch at 128^2 multiplies a chunk in ~0.5 us but needs ~1.5 us to fetch one, so depth hides what
 //   a single chunk in flight cannot.
-template <int NW, int RPW, int NSTAGE>
+//   KS = 2 (round 4, <8, 1, 3, 2>): K split -- waves w and w + NW / 2 share an image row, each multiplies ONE 16-channel k-step of every
+//   32-channel chunk (the decomposition of conv3x3_halo_ks_kernel on LDS-DMA staging with three stages): 4-row tiles with eight waves, for
+//   the per-frame convolutions of the 128^2 level, where four waves of one row each (one per SIMD) cannot hide their fragment reads.
+//   After the last chunk the pair exchanges one 32-cout accumulator through LDS and each wave finishes 32 couts of its row.
+template <int NW, int RPW, int NSTAGE, int KS = 1>
 __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(ConvArgs a, int nTiles, int tilesPerXcd) {
     prefetch_kernargs<sizeof(ConvArgs) + 8>();
     using E = bf16_t;
-    constexpr int TH = NW * RPW, HWP = 34;                 // tile rows, halo pitch in pixels
+    static_assert(KS == 1 || (KS == 2 && RPW == 1 && NSTAGE == 3 && NW % 2 == 0), "K split: one-tile form with one row per wave");
+    constexpr int ROWW = NW / KS;                          // waves along the rows of the tile
+    constexpr int KSTEPS = 2 / KS;                         // 16-channel k-steps of a chunk this wave multiplies
+    constexpr int TH = ROWW * RPW, HWP = 34;               // tile rows, halo pitch in pixels
     constexpr int HALO_ROWS = (TH + 2) * HWP;              // staged pixels
     constexpr int HALO_INSTR = (HALO_ROWS + 15) / 16;      // DMA wave-instructions of 16 rows x 64 B
     constexpr int W_INSTR = 64 * 9 / 16;                   // 36
@@ -1008,6 +1015,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = KS == 1 ? wave : wave % ROWW, kpart = KS == 1 ? 0 : wave / ROWW;      // row group / k-step of this wave
     const int lr = lane & 31, lh = lane >> 5;
     const int taps = a.KT * 9, pt = a.KT / 2;
     const int chunksPerTap = a.CinTot / 32;
@@ -1132,13 +1140,14 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
 
     // ---- fragment read offsets (per lane, fixed).  A: weight row tap9 * 64 + cf * 32 + lr, chunk 2 s + lh;
     // B: halo row (2 wave + j + kh) * 34 + kw + lr, same chunk; XOR terms as written by the DMA.
-    unsigned aoff[2], boff[3][2];
+    unsigned aoff[KSTEPS], boff[3][KSTEPS];
 #pragma unroll
-    for (int s_ = 0; s_ < 2; ++s_) {
-        aoff[s_] = (unsigned)(HALO_BYTES + lr * 64 + (((2 * s_ + lh) ^ ((lr >> 2) & 3)) << 4));
+    for (int si = 0; si < KSTEPS; ++si) {
+        const int s_ = KS == 1 ? si : kpart;               // K split: the wave's own k-step
+        aoff[si] = (unsigned)(HALO_BYTES + lr * 64 + (((2 * s_ + lh) ^ ((lr >> 2) & 3)) << 4));
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw)
-            boff[kw][s_] = (unsigned)((RPW * wave * HWP + kw + lr) * 64 + (((2 * s_ + lh) ^ (((kw + lr) >> 2) & 3)) << 4));
+            boff[kw][si] = (unsigned)((RPW * wr * HWP + kw + lr) * 64 + (((2 * s_ + lh) ^ (((kw + lr) >> 2) & 3)) << 4));
     }
 
     f32x16 acc[RPW][2];            // [row j][cout fragment]
@@ -1155,26 +1164,30 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
     auto compute_as = [&](int stage, auto revTag) {
         constexpr bool REV = decltype(revTag)::value;      // walk the column taps right to left (experiment: de-phase wave pairs)
         const char* sb = smem + stage * STAGE_BYTES;
-        uint4 fb[2][RPW + 2][2];   // [set][halo row RPW wave + h][k-step]
-        uint4 fa[2][2][2];         // [set][cout fragment][k-step]
+        uint4 fb[2][RPW + 2][KSTEPS];   // [set][halo row RPW wave + h][k-step]
+        uint4 fa[2][2][KSTEPS];         // [set][cout fragment][k-step]
         auto load_b = [&](int set, int kw) {
 #pragma unroll
             for (int h = 0; h < RPW + 2; ++h)
 #pragma unroll
-                for (int s_ = 0; s_ < 2; ++s_)
+                for (int s_ = 0; s_ < KSTEPS; ++s_)
                     fb[set][h][s_] = *reinterpret_cast<const uint4*>(sb + h * (HWP * 64) + boff[kw][s_]);
         };
         auto load_a = [&](int set, int kh, int kw) {
 #pragma unroll
             for (int cf = 0; cf < 2; ++cf)
 #pragma unroll
-                for (int s_ = 0; s_ < 2; ++s_)
+                for (int s_ = 0; s_ < KSTEPS; ++s_)
                     fa[set][cf][s_] = *reinterpret_cast<const uint4*>(sb + (kh * 3 + kw) * 4096 + cf * 2048 + aoff[s_]);
+        };
+        auto mma = [&](const uint4 (&fa_)[KSTEPS], const uint4 (&fb_)[KSTEPS], f32x16& c) {
+            if constexpr (KS == 1) Mma<E>::run(fa_, fb_, c);
+            else c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa_[0]), __builtin_bit_cast(bf16x8, fb_[0]), c, 0, 0, 0);
         };
         auto KW = [](int q) { return REV ? 2 - q : q; };
         load_b(0, KW(0));
         load_a(0, 0, KW(0));
-        __builtin_amdgcn_sched_group_barrier(0x100, 2 * (RPW + 2) + 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, KSTEPS * (RPW + 2) + 2 * KSTEPS, 0);
 #pragma unroll
         for (int step = 0; step < 9; ++step) {
             const int kq = step / 3, kh = step % 3;
@@ -1187,13 +1200,13 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
 #pragma unroll
             for (int j = 0; j < RPW; ++j)
 #pragma unroll
-                for (int cf = 0; cf < 2; ++cf) Mma<E>::run(fa[step & 1][cf], fb[kq & 1][j + kh], acc[j][cf]);
+                for (int cf = 0; cf < 2; ++cf) mma(fa[step & 1][cf], fb[kq & 1][j + kh], acc[j][cf]);
             if (FLAIR_DBG(a) == 17) __builtin_amdgcn_s_setprio(0);
             if (step < 8) {
-                if (nkh == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2 * (RPW + 2) + 4, 0);
-                else __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                if (nkh == 0) __builtin_amdgcn_sched_group_barrier(0x100, KSTEPS * (RPW + 2) + 2 * KSTEPS, 0);
+                else __builtin_amdgcn_sched_group_barrier(0x100, 2 * KSTEPS, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x8, 4 * RPW, 0);
+            __builtin_amdgcn_sched_group_barrier(0x8, 2 * KSTEPS * RPW, 0);
         }
     };
     auto compute = [&](int stage) {
@@ -1221,7 +1234,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
         // convolution with residual).  Now all residual pieces of the wave are requested in one batch up front
         // (the staging fragments are dead, the registers exist) and the waits are counted; the frame bias is part of the tile's
         // bias slot in LDS (bias_request).
-        const long p0w = ((long)tl.t * H + tl.h0 + RPW * wave) * W + tl.w0;              // first pixel of the wave's rows (wave-uniform)
+        const long p0w = ((long)tl.t * H + tl.h0 + RPW * wr) * W + tl.w0;                // first pixel of the wave's rows (wave-uniform)
         const int cl = 8 * lh;                                                           // this lane's cout offset inside a 16-cout half
         const unsigned yLdB = (unsigned)a.yLd * 2u, rLdB = (unsigned)a.res0Ld * 2u;
         const unsigned span = (unsigned)(RPW * W);                                       // pixels the wave's offsets stay below
@@ -1319,7 +1332,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
     auto epilogue_plain_as = [&](const DmaTile& tl, int biasSlot, auto actTag) {
         constexpr int ACT = decltype(actTag)::value;       // 0: max(v, slope v)   1: DCN offsets / masks   2: SiLU
         const float slope = a.act == FLAIR_ACT_NONE ? 1.f : a.act == FLAIR_ACT_RELU ? 0.f : a.act == FLAIR_ACT_LRELU01 ? 0.1f : 0.2f;
-        const long p0 = ((long)tl.t * H + tl.h0 + RPW * wave) * W + tl.w0 + lr;          // this lane's pixel in row j = 0
+        const long p0 = ((long)tl.t * H + tl.h0 + RPW * wr) * W + tl.w0 + lr;            // this lane's pixel in row j = 0
         const int cl = 8 * lh;                                                           // this lane's cout offset inside a 16-cout half
         E* yb = reinterpret_cast<E*>(a.y) + p0 * a.yLd + tl.co0 + cl;
         const E* r0b = a.res0 ? reinterpret_cast<const E*>(a.res0) + p0 * a.res0Ld + tl.co0 + cl : nullptr;
@@ -1327,10 +1340,10 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
         const float* bl = reinterpret_cast<const float*>(smem + BIAS_OFF + (biasSlot & 1) * 256) + cl;
         const float scale = a.outScale;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2 / KS; ++i)                                                 // K split: the wave's sum sits in acc[.][0], its couts start at 32 * kpart
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
-                const int cofs = i * 32 + 16 * jj;                                       // cout offset of this group inside the tile
+                const int cofs = (KS == 1 ? i : kpart) * 32 + 16 * jj;                   // cout offset of this group inside the tile
                 if (tl.co0 + cofs >= a.Cout) continue;                                   // wave-uniform: the whole 16-cout group is padding
                 // (Cout % 8 == 0) the upper 8 couts of the group may be padding: those lanes still take part in the
                 // v_permlane32_swap below (a swap under a divergent branch hands the active half garbage), only their
@@ -1402,7 +1415,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
     // then find their lines in the L2 instead of paying a trip to HBM with every wave of the CU waiting.  No register
     // receives data, so nothing can be clobbered; the pieces are older than that chunk's DMA and retire with it.
     auto prefetch_res = [&](const DmaTile& tl) {
-        const long p0w = ((long)tl.t * H + tl.h0 + RPW * wave) * W + tl.w0;
+        const long p0w = ((long)tl.t * H + tl.h0 + RPW * wr) * W + tl.w0;
         const u32x4_t rd = make_desc(reinterpret_cast<const char*>(a.res0) + (p0w * a.res0Ld + tl.co0) * 2, (unsigned)(RPW * W * a.res0Ld) * 2u);
 #pragma unroll
         for (int jj = 0; jj < (RPW + 1) / 2; ++jj) {
@@ -1465,6 +1478,30 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
                 walk_next(cur.t, wk);
             }
             if (FLAIR_DBG(a) != 11) compute(n % 3);
+        }
+        if constexpr (KS == 2) {
+            // ---- sum the two k-steps of every row: the wave of k-step 0 finishes cout fragment 0, its partner fragment 1; each parks the
+            // fragment it gives away in LDS (stage 0: every wave is past its last fragment read after the barrier)
+            __syncthreads();
+            float* red = reinterpret_cast<float*>(smem);
+            float* mine = red + (wave * 64 + lane) * 16;
+            const float* theirs = red + ((wave ^ ROWW) * 64 + lane) * 16;                // partner: same row, other k-step (ROWW is a power of two)
+            static_assert((ROWW & (ROWW - 1)) == 0, "partner by xor");
+            if (kpart == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; r += 4) *reinterpret_cast<float4*>(mine + r) = make_float4(acc[0][1][r], acc[0][1][r + 1], acc[0][1][r + 2], acc[0][1][r + 3]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; r += 4) *reinterpret_cast<float4*>(mine + r) = make_float4(acc[0][0][r], acc[0][0][r + 1], acc[0][0][r + 2], acc[0][0][r + 3]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][0][r] = acc[0][1][r];                 // the kept fragment moves to slot 0 (the epilogue reads slot 0)
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; r += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(theirs + r);
+                acc[0][0][r] += v.x; acc[0][0][r + 1] += v.y; acc[0][0][r + 2] += v.z; acc[0][0][r + 3] += v.w;
+            }
         }
         if (FLAIR_DBG(a) != 13) epilogue(cur, 0);
         return;
@@ -1531,9 +1568,9 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
     }
 }
 
-template <int NW, int RPW, int NSTAGE>
+template <int NW, int RPW, int NSTAGE, int KS = 1>
 int launch_dma(const ConvArgs& a0, hipStream_t s) {
-    constexpr int TH = NW * RPW;
+    constexpr int TH = NW / KS * RPW;
     ConvArgs a = a0;
     a.nCoTiles = cdiv(a.Cout, 64);
     static const int tfast = getenv("FLAIR_DMA_TFAST") ? atoi(getenv("FLAIR_DMA_TFAST")) : 1;
@@ -1552,10 +1589,10 @@ int launch_dma(const ConvArgs& a0, hipStream_t s) {
     if (NSTAGE == 3) FLAIR_CHECK(nTiles <= grid, "flair_conv_nhwc: the three-stage form runs one tile per workgroup");
     static LdsAttrOnce attr;
     {
-        const hipError_t e = flair_max_lds_once(attr, reinterpret_cast<const void*>(&conv3x3_dma_kernel<NW, RPW, NSTAGE>));
+        const hipError_t e = flair_max_lds_once(attr, reinterpret_cast<const void*>(&conv3x3_dma_kernel<NW, RPW, NSTAGE, KS>));
         FLAIR_CHECK(e == hipSuccess, "flair_conv_nhwc: hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
-    hipLaunchKernelGGL((conv3x3_dma_kernel<NW, RPW, NSTAGE>), dim3(grid), dim3(64 * NW), lds, s, a, nTiles, tilesPerXcd);
+    hipLaunchKernelGGL((conv3x3_dma_kernel<NW, RPW, NSTAGE, KS>), dim3(grid), dim3(64 * NW), lds, s, a, nTiles, tilesPerXcd);
     FLAIR_LAUNCH_CHECK();
     return FLAIR_OK;
 }
@@ -1908,10 +1945,12 @@ int choose_variant(const ConvArgs& a) {
         // fetch (~4 us: every CU pulls its 58 KB at once after the boundary invalidated the L2s) + epilogue / drain (~3 us)
         // whatever the staging mechanism: <8 rows> 12.6 vs 13.6 us on 64->64, equal on 224->64; <4 rows> 14.3 vs 11.9 us (one
         // wave per SIMD does not hide the per-chunk DMA round trips that 8 K-split waves do), hence off by default.
+        // 3 (round 4): the <4 rows> form with EIGHT waves, K split like the K-split kernel (<8, 1, 3, KS = 2>): correct, +0.5 ms per step against
+        // the register-staged K-split kernel (77.5 / 77.7 -> 78.1 / 78.1, same box): LDS-DMA staging does not pay on one-tile launches of this size.
         static const int dmaFrame = getenv("FLAIR_CONV_DMA_FRAME") ? atoi(getenv("FLAIR_CONV_DMA_FRAME")) : 1;
         const bool dmaOk = a.esz == 2 && ks && a.act != FLAIR_ACT_GELU;
         if (per * cdiv(a.H, 8) >= 256) return ks && per * cdiv(a.H, 8) <= 256 ? (dmaOk && dmaFrame >= 1 && a.H % 8 == 0 ? 9 : 6) : 3;
-        if (per * cdiv(a.H, 4) >= 256) return ks && per * cdiv(a.H, 4) <= 256 ? (dmaOk && dmaFrame >= 2 && a.H % 4 == 0 ? 10 : 7) : 4;
+        if (per * cdiv(a.H, 4) >= 256) return ks && per * cdiv(a.H, 4) <= 256 ? (dmaOk && dmaFrame >= 3 && a.H % 4 == 0 ? 11 : dmaOk && dmaFrame == 2 && a.H % 4 == 0 ? 10 : 7) : 4;
         return 5;
     }
     const long tiles128 = (long)cdiv(a.P, 128) * cdiv(a.Cout, 128);
@@ -1958,6 +1997,7 @@ int dispatch(const ConvArgs& a0, hipStream_t s) {
         }
         case 9: return launch_dma<8, 1, 2>(a, s);
         case 10: return launch_dma<4, 1, 3>(a, s);
+        case 11: return launch_dma<8, 1, 3, 2>(a, s);
         default: return launch_halo<E, 2, 1, 1>(a, s);
     }
 }
