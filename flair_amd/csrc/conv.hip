@@ -996,9 +996,8 @@ struct DmaTile {
 //   32-channel chunk (the decomposition of conv3x3_halo_ks_kernel on LDS-DMA staging with three stages): 4-row tiles with eight waves, for
 //   the per-frame convolutions of the 128^2 level, where four waves of one row each (one per SIMD) cannot hide their fragment reads.
 //   After the last chunk the pair exchanges one 32-cout accumulator through LDS and each wave finishes 32 couts of its row.
-template <int NW, int RPW, int NSTAGE, int KS = 1>
-__global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(ConvArgs a, int nTiles, int tilesPerXcd) {
-    prefetch_kernargs<sizeof(ConvArgs) + 8>();
+template <int NW, int RPW, int NSTAGE, int KS>
+__device__ __forceinline__ void conv3x3_dma_body(const ConvArgs& a, int nTiles, int tilesPerXcd) {
     using E = bf16_t;
     static_assert(KS == 1 || (KS == 2 && RPW == 1 && NSTAGE == 3 && NW % 2 == 0), "K split: one-tile form with one row per wave");
     constexpr int ROWW = NW / KS;                          // waves along the rows of the tile
@@ -1568,6 +1567,17 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(Conv
     }
 }
 
+template <int NW, int RPW, int NSTAGE>
+__global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_kernel(ConvArgs a, int nTiles, int tilesPerXcd) {
+    prefetch_kernargs<sizeof(ConvArgs) + 8>();
+    conv3x3_dma_body<NW, RPW, NSTAGE, 1>(a, nTiles, tilesPerXcd);
+}
+template <int NW, int RPW, int NSTAGE>          // the K-split form under its own name (rocprofv3 rows of the other forms keep theirs)
+__global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void conv3x3_dma_ks_kernel(ConvArgs a, int nTiles, int tilesPerXcd) {
+    prefetch_kernargs<sizeof(ConvArgs) + 8>();
+    conv3x3_dma_body<NW, RPW, NSTAGE, 2>(a, nTiles, tilesPerXcd);
+}
+
 template <int NW, int RPW, int NSTAGE, int KS = 1>
 int launch_dma(const ConvArgs& a0, hipStream_t s) {
     constexpr int TH = NW / KS * RPW;
@@ -1589,10 +1599,14 @@ int launch_dma(const ConvArgs& a0, hipStream_t s) {
     if (NSTAGE == 3) FLAIR_CHECK(nTiles <= grid, "flair_conv_nhwc: the three-stage form runs one tile per workgroup");
     static LdsAttrOnce attr;
     {
-        const hipError_t e = flair_max_lds_once(attr, reinterpret_cast<const void*>(&conv3x3_dma_kernel<NW, RPW, NSTAGE, KS>));
+        const void* fn;
+        if constexpr (KS == 1) fn = reinterpret_cast<const void*>(&conv3x3_dma_kernel<NW, RPW, NSTAGE>);
+        else fn = reinterpret_cast<const void*>(&conv3x3_dma_ks_kernel<NW, RPW, NSTAGE>);
+        const hipError_t e = flair_max_lds_once(attr, fn);
         FLAIR_CHECK(e == hipSuccess, "flair_conv_nhwc: hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
-    hipLaunchKernelGGL((conv3x3_dma_kernel<NW, RPW, NSTAGE, KS>), dim3(grid), dim3(64 * NW), lds, s, a, nTiles, tilesPerXcd);
+    if constexpr (KS == 1) hipLaunchKernelGGL((conv3x3_dma_kernel<NW, RPW, NSTAGE>), dim3(grid), dim3(64 * NW), lds, s, a, nTiles, tilesPerXcd);
+    else hipLaunchKernelGGL((conv3x3_dma_ks_kernel<NW, RPW, NSTAGE>), dim3(grid), dim3(64 * NW), lds, s, a, nTiles, tilesPerXcd);
     FLAIR_LAUNCH_CHECK();
     return FLAIR_OK;
 }
