@@ -118,9 +118,10 @@ __device__ __forceinline__ float fast_tanh(float x) {
 // 16 mantissa bits: |error| <= 2^-9 * sum_k |w_k v_k| <= 2^-9 max|v| per blended value, the size of the bf16 rounding the value gets
 // anyway when it is staged for the MFMA; f32 tensors keep the exact path.
 // PFD = gather register sets in flight (2: the loads of step k+1 fly while step k is blended; 3: also step k+2 --
-// for the c = 128 tiles, where only 8 wavefronts per CU exist to hide the gather round trip).
+// for the c = 128 tiles, where only 8 wavefronts per CU exist to hide the gather round trip; 1 (round 4, the c = 64 per-frame form): the
+// loads of a step are waited for in the same step, at 64 VGPRs, and a SECOND workgroup on the CU hides them).
 template <typename E, int NCF, int NPF, int TPP, bool ACTIVATED, bool ONEFRAME, int PFD, bool DOT2>
-__global__ __launch_bounds__(32 * NPF * TPP, (NCF >= 4 ? 32 * NPF * TPP / 256 : 4)) void dcn_kernel(DcnArgs a) {
+__global__ __launch_bounds__(32 * NPF * TPP, (PFD == 1 ? 8 : NCF >= 4 ? 32 * NPF * TPP / 256 : 4)) void dcn_kernel(DcnArgs a) {
     prefetch_kernargs<sizeof(DcnArgs)>();
     constexpr int NT = 32 * NPF * TPP, NW = NT / 64;
     constexpr int TP = 32 * NPF, TC = 32 * NCF, CPR = TPP;
@@ -531,9 +532,9 @@ __global__ __launch_bounds__(32 * NPF * TPP, (NCF >= 4 ? 32 * NPF * TPP / 256 : 
 
 }  // namespace
 
-template <typename E, int NCF, int NPF, int TPP, bool ACTIVATED, bool ONEFRAME, bool DOT2>
+template <typename E, int NCF, int NPF, int TPP, bool ACTIVATED, bool ONEFRAME, bool DOT2, int PFDSEL = 0>
 static int launch_dcn_v2(const DcnArgs& a0, hipStream_t stream) {
-    constexpr int PFD = NCF >= 4 && TPP <= 8 ? 3 : 2;
+    constexpr int PFD = PFDSEL > 0 ? PFDSEL : NCF >= 4 && TPP <= 8 ? 3 : 2;
     DcnArgs a = a0;
     if (ONEFRAME) {      // resources cover one frame: rows outside the image fall outside the resource
         const unsigned long long half = a.Cin / 2, hw = (unsigned long long)a.H * a.W;
@@ -558,6 +559,14 @@ template <typename E, int NCF, int NPF, int TPP, bool ACTIVATED, bool ONEFRAME>
 static int launch_dcn_v(const DcnArgs& a, hipStream_t stream) {
     if constexpr (sizeof(E) == 2 && ACTIVATED && ONEFRAME) {
         static const bool dot2 = !(getenv("FLAIR_DCN_DOT2") && atoi(getenv("FLAIR_DCN_DOT2")) == 0);
+        if constexpr (NCF == 2 && NPF == 4) {
+            // ONE gather register set (64 VGPRs instead of 106) so that TWO 16-wave workgroups share a CU (2 x 78 KB of LDS, 8 waves per SIMD): at
+            // 106 VGPRs a 256^2 frame's 512 workgroups ran as two rounds of one workgroup per CU, every barrier idling the CU for the skew of
+            // its 16 waves; now the other workgroup's waves fill the barrier skew and the gather round trips that the second register set hid.
+            // Alignment family 7.86 / 7.98 -> 7.03 / 7.10 ms per step, step 78.07 / 77.61 -> 77.13 / 77.00 ms (same box).  FLAIR_DCN_PFD1=0: two sets.
+            static const bool pfd1 = !(getenv("FLAIR_DCN_PFD1") && atoi(getenv("FLAIR_DCN_PFD1")) == 0);
+            if (dot2 && pfd1) return launch_dcn_v2<E, NCF, NPF, TPP, ACTIVATED, ONEFRAME, true, 1>(a, stream);
+        }
         if (dot2) return launch_dcn_v2<E, NCF, NPF, TPP, ACTIVATED, ONEFRAME, true>(a, stream);
     }
     return launch_dcn_v2<E, NCF, NPF, TPP, ACTIVATED, ONEFRAME, false>(a, stream);
