@@ -141,6 +141,35 @@ def test_hip_graph_replay_matches_eager(dev):
     m.enable_hip_graph(False)
 
 
+@pytest.mark.gpu
+def test_two_clips_in_one_call_replay_two_graphs_bit_identically(dev):
+    """B = 2 with enable_hip_graph(): each clip of the batch gets its own captured graph (the key carries the clip index; one shared
+    entry would be evicted and re-captured by the other clip on every forward), and the batched output equals the two single-clip
+    eager forwards bit for bit -- on the capturing call and on pure replays with new latents."""
+    _, m = build_pair(SMALL)
+    m = m.to(dev)
+    m.convert_to_fp16()
+    T, S, B = 4, 32, 2
+    lrs = [_inputs(T, S, seed=11 + b)[1].to(dev) for b in range(B)]
+    lr2 = torch.cat(lrs)                                            # (B, T, 3, S, S): ONE device tensor for the batched calls
+    rounds = []
+    for r, tval in enumerate((371, 64, 903)):
+        xs = [(_inputs(T, S, seed=11 + b)[0] + 0.02 * (r + 1) * (b + 1)).to(dev) for b in range(B)]
+        t = torch.full((T,), tval, dtype=torch.long, device=dev)
+        single = [m(xs[b], t, low_res_input=lrs[b], num_frames=T, vsrpp_weights=1.0).clone() for b in range(B)]
+        rounds.append((torch.cat(xs), torch.cat([t, t]), torch.cat(single)))
+    m.enable_hip_graph()
+    graphs = []
+    for x2, t2, ref in rounds:
+        y = m(x2, t2, low_res_input=lr2, num_frames=T, vsrpp_weights=1.0)
+        torch.cuda.synchronize()
+        assert torch.equal(y, ref)
+        assert len(m._graphs) == B
+        graphs.append([ent["graph"] for ent in m._graphs.values()])
+    assert all(g0 is g1 for g0, g1 in zip(graphs[0], graphs[1])) and all(g0 is g2 for g0, g2 in zip(graphs[0], graphs[2]))
+    m.enable_hip_graph(False)
+
+
 def test_reference_checkpoint_ingest(tmp_path):
     """CPU: a reference-format checkpoint file (fp32 state dict with the reference's keys) loads through the
     safe loader; wrong files are refused."""
