@@ -171,3 +171,33 @@ def test_conv_on_clips_larger_than_2gib(dev):
     w1[7, k, 0, 0, 0] = -2.0
     y1 = ops.conv(x, ops.pack_conv_weight(w1, [(C, C)], torch.bfloat16).to(dev), None, 8, (1, 1, 1))
     assert torch.equal(y1[..., 7], -2.0 * x[..., k])
+
+
+@pytest.mark.parametrize("c,side", [(64, 256), (128, 128)])
+def test_benched_alignment_forms_reduce_to_a_shifted_convolution_full_size(dev, c, side):
+    """The bf16 per-frame forms the bench spends its alignment time in (c = 64 at 256^2: two workgroups per CU, one gather register
+    set, v_dot2c blend; c = 128 at 128^2: 64-pixel tiles x 16 threads per pixel), activated offsets: with every residue the same
+    INTEGER (dy, dx), unit masks and no flow the bilinear weights are exactly 0 / 1, so away from the border the deformable
+    alignment IS the plain 3x3 convolution of the shifted features -- at any size."""
+    ops = _ops()
+    G, dy, dx = 16, 2, -3
+    g = torch.Generator().manual_seed(7 + c)
+    bf = torch.bfloat16
+    x0 = torch.randn(1, side, side, c, generator=g).to(bf).to(dev)
+    x1 = torch.randn(1, side, side, c, generator=g).to(bf).to(dev)
+    w = (torch.randn(c, 2 * c, 3, 3, generator=g) / math.sqrt(18 * c)).to(bf).float()
+    b = (torch.randn(c, generator=g) * 0.1).to(dev)
+    wp = ops.pack_conv_weight(w, [(2 * c, 2 * c)], bf).to(dev)
+    raw = torch.empty(1, side, side, 27 * G)
+    per_tap = raw.view(1, side, side, 9, 3 * G)                    # tap-major: [2 g + {0, 1}] = (dy, dx), [2 G + g] = mask
+    per_tap[..., 0:2 * G:2] = float(dy)
+    per_tap[..., 1:2 * G:2] = float(dx)
+    per_tap[..., 2 * G:] = 1.0
+    y = ops.dcn_align(x0, x1, raw.to(bf).to(dev), None, None, wp, b, c, raw_activated=True)
+    shifted = [torch.roll(t, shifts=(-dy, -dx), dims=(1, 2)).contiguous() for t in (x0, x1)]   # shifted(h, w) = x(h + dy, w + dx)
+    plain = ops.conv(shifted, wp, b, c, (1, 3, 3))
+    torch.cuda.synchronize()
+    m = max(abs(dy), abs(dx)) + 1
+    got, ref = y[:, m:-m, m:-m].float(), plain[:, m:-m, m:-m].float()
+    assert (got - ref).abs().max().item() <= 1.6e-2 * ref.abs().max().item()
+    assert (got - ref).pow(2).mean().sqrt().item() <= 4e-3 * ref.pow(2).mean().sqrt().item()
