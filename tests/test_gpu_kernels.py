@@ -501,7 +501,7 @@ def test_dcn_offset_activation_epilogue(dev, dtype, path):
 
 
 @pytest.mark.parametrize("cout,act,shape", [(432, 4, (1, 16, 32)), (432, 4, (2, 24, 64)), (64, 2, (1, 8, 32)), (200, 0, (3, 8, 96)),
-                                            (8, 1, (1, 16, 32)), (72, 3, (1, 32, 32)), (432, 4, (1, 128, 128))])
+                                            (8, 1, (1, 16, 32)), (72, 3, (1, 32, 32)), (432, 4, (1, 128, 128)), (432, 4, (1, 256, 256))])
 def test_conv_resident_input(dev, cout, act, shape):
     """conv_resident_kernel (round 4: flair_conv_chain without a first stage on bf16 c = 64 inputs -- the c -> 27*G offset
     convolution): halo resident in LDS, weight ring by LDS-DMA, epilogue of block b beside the MFMAs of block b + 1.
