@@ -124,7 +124,9 @@ int flair_conv_variant(const flair_conv_params* p);
  * Y = (actB(conv3x3(M, WB) + biasB) + res0 + res1) * out_scale        (CoutB channels)
  * per frame, zero "same" padding on both convolutions.  With WA == NULL there is no stage A: the
  * single input segment (C channels) is staged once per tile and kept resident while CoutB is walked
- * in blocks of 64 (wide-output convolutions: the c -> 27*G offset convolution).
+ * in blocks of 64 (wide-output convolutions: the c -> 27*G offset convolution).  For bf16, C = 64, W % 32 == 0,
+ * H % 8 == 0, CoutB % 8 == 0 and no residual inputs this form runs on conv_resident_kernel (round 4: halo by LDS-DMA,
+ * three-stage weight ring, the epilogue of one 64-cout block issued between the MFMAs of the next); same results.
  * Replaces pairs of dependent launches of the BasicVSR++ recurrence: conv_offset[2]+[4] and
  * conv_offset[4]+[6] of SecondOrderDeformableAlignment (unet_new.py:859-867), conv1+conv2 of mmedit's
  * ResidualBlockNoBN inside ResidualBlocksWithInputConv with its residual adds (unet_new.py:659-668,
