@@ -211,3 +211,54 @@ def test_helper_get_crop_face_runs_detector_alignment_and_crop(dev):
         crop = ofw.warp_affine_cubic(img, M, (128, 128), border=(135.0, 133.0, 132.0))
         ref = torch.from_numpy(((crop / 255.0 - 0.5) / 0.5).clip(-1, 1)).permute(2, 0, 1)
         assert (faces[k].cpu() - ref).abs().max().item() <= 2e-3
+
+
+@pytest.mark.gpu
+def test_helper_get_crop_face_selection_rules_with_fixed_detections(dev):
+    """The host logic of get_crop_face (face_restoration_helper.py:122-224) on detections handed in by a stub detector: the first /
+    largest / centre face, the eye-distance filter, frames without a detection dropped from the result, the template offsets and
+    scale, and the crop = get_crop_face_from_affine_matrices of the chosen matrices."""
+    from flair_amd.guided_diffusion.face_restoration_helper import FaceRestoreHelper
+    from flair_amd.guided_diffusion.retinaface_utils import estimate_affine_partial
+
+    def face(cx, cy, size, score):
+        # box + five landmarks of a face of the given size centred at (cx, cy): the 512-template scaled and shifted
+        tpl = np.array([[192.98138, 239.94708], [318.90277, 240.1936], [256.63416, 314.01935], [201.26117, 371.41043],
+                        [313.08905, 371.15118]]) / 512.0 - 0.5
+        lm = tpl * size + np.array([cx, cy])
+        return np.concatenate([[cx - size / 2, cy - size / 2, cx + size / 2, cy + size / 2, score], lm.reshape(-1)]).astype(np.float32)
+
+    small_first = face(30.0, 34.0, 24.0, 0.99)          # first in the list, small, far from the centre
+    large = face(84.0, 40.0, 56.0, 0.9)                 # the largest box
+    central = face(66.0, 62.0, 30.0, 0.8)               # nearest the centre of a 128 x 128 frame
+    per_frame = [np.stack([small_first, large, central]), np.zeros((0, 15), np.float32), np.stack([central])]
+
+    class StubDetector:
+        def batched_detect_faces(self, frames, conf_threshold=0.8, nms_threshold=0.4, use_origin_size=True, pre=None):
+            assert tuple(frames.shape) == (3, 3, 128, 128) and conf_threshold == 0.5 and pre == (127.5, 127.5, 0.0, 255.0)
+            return [d for d in per_frame if len(d)]      # the reference's detector skips frames without a face (retinaface.py:393-395)
+
+    helper = FaceRestoreHelper(face_size=128, device=dev, face_det=StubDetector())
+    g = torch.Generator().manual_seed(3)
+    x = (torch.rand(3, 3, 128, 128, generator=g) * 2 - 1).to(dev)
+    tpl = helper.face_template
+
+    def lms(row):
+        return row[5:15].reshape(5, 2)
+    for kw, want in ((dict(), small_first), (dict(only_keep_largest=True), large), (dict(only_center_face=True), central)):
+        faces, mats, idx = helper.get_crop_face(x, **kw)
+        assert idx == [0, 1] and len(mats) == 2            # two results: the detector's list pairs with the frames in order
+        assert np.allclose(mats[0], estimate_affine_partial(lms(want), tpl))
+        assert np.allclose(mats[1], estimate_affine_partial(lms(central), tpl))
+        ref = helper.get_crop_face_from_affine_matrices(x[idx].contiguous(), mats)
+        assert torch.equal(faces, ref) and tuple(faces.shape) == (2, 3, 128, 128)
+    # eye distance: small_first's eyes are 24 * 0.246 = 5.9 px apart, large's 13.8, central's 7.4
+    faces, mats, idx = helper.get_crop_face(x, eye_dist_threshold=7.0)
+    assert np.allclose(mats[0], estimate_affine_partial(lms(large), tpl))
+    faces, mats, idx = helper.get_crop_face(x, eye_dist_threshold=20.0)
+    assert faces is None and mats is None and idx is None
+    # template scale and offsets
+    faces, mats, idx = helper.get_crop_face(x, only_center_face=True, face_template_resize=0.5, face_template_x_offset=4.0, face_template_y_offset=-2.0)
+    assert np.allclose(mats[0], estimate_affine_partial(lms(central), (tpl + np.array([4.0, -2.0])) * 0.5))
+    with pytest.raises(NotImplementedError):
+        helper.get_crop_face(x, resize=256)
