@@ -829,6 +829,328 @@ int launch_resident(const ChainArgs& c, hipStream_t s) {
     return pick(std::integral_constant<int, 0>{});
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Pair of 3x3 convolutions c = 64 -> 64 -> 64 on LDS-DMA staging (round 4; FLAIR_CONV_PAIR=0 selects the older form): the HASA form of
+// conv_chain_kernel above spends 7.8 k cycles of its 32.5 k on the first fetch (load -> register -> ds_write -> barrier), 11.0 k on
+// a stage-A K loop whose MFMA floor is 6.9 k (two barriers per chunk), 4.1 k on moving the intermediate to LDS in 8-byte pieces and
+// 7.2 k on stage B (floor 4.6 k) -- tools/probes/chain_probe.py.  Here, as in conv_resident_kernel:
+//   * the (8+4) x 36 input halo of both 32-channel chunks arrives ONCE by LDS-DMA (2 x 27 KB, 64-byte rows, 16-byte pieces
+//     XOR-swizzled by the pixel column on the source address);
+//   * the four weight stages (A chunk 0 / 1, B chunk 0 / 1; 36 KB each) go through two ring slots, the next stage in flight while one is
+//     multiplied, counted vmcnt, ONE s_barrier per stage;
+//   * the intermediate (10 x 34 pixels x 64 channels, activation applied, zero outside the image, rounded to bf16 like the unfused
+//     pair) is written over the input halo in 16-byte pieces (v_permlane32_swap gives a lane 8 consecutive channels) in the layout
+//     stage B reads conflict-free;
+//   * stage B = conv3x3_dma_kernel's one-row form, epilogue from the accumulators with both residual inputs requested before it.
+// bf16, one 64-channel input segment, CoutB = 64, W % 32 == 0, H % 8 == 0, activations none / ReLU / LeakyReLU(0.1).
+struct PairArgs {
+    const void* x; int xLd; unsigned xBytes;      // one input frame
+    const void* wA; const void* wB; unsigned wBytes;
+    const float* biasA; const float* biasB;
+    int actA, actB;
+    float outScale;
+    const void* res0; const void* res1; int res0Ld, res1Ld;
+    void* y; int yLd;
+    int T, H, W;
+};
+
+__global__ __launch_bounds__(512, 2) void conv_pair_kernel(PairArgs a) {
+    prefetch_kernargs<sizeof(PairArgs)>();
+    using E = bf16_t;
+    constexpr int NW = 8;
+    constexpr int WIN = 36, IN_INSTR = 27, IN_IMG = IN_INSTR * 1024;          // 12 x 36 = 432 halo pixels = 27 DMA instructions per chunk
+    constexpr int WMID = 34, NPMID = 10 * WMID, MID_IMG = 22 * 1024;           // 340 intermediate pixels per chunk image (over the halo)
+    constexpr int WINSTR = 36, SLOT = WINSTR * 1024;
+    constexpr int RING = 2 * IN_IMG, BIAS = RING + 2 * SLOT;                   // + 2 KB: biases of stage A | stage B
+    constexpr int NH = (IN_INSTR + NW - 1) / NW, NWS = (WINSTR + NW - 1) / NW; // 4, 5 DMA instructions per wave
+    constexpr int NITEM = (NPMID + 31) / 32;                                   // 11 fragments of 32 intermediate pixels
+    static_assert(2 * MID_IMG <= RING && NITEM <= 2 * NW, "layout");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int lrow = lane >> 2, lchunk = lane & 3;
+    const int tilesW = a.W / 32, perFrame = tilesW * (a.H / 8);
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int t = bid / perFrame, tile = bid - t * perFrame;
+    const int h0 = (tile / tilesW) * 8, w0 = (tile % tilesW) * 32;
+
+    const unsigned ldB = (unsigned)a.xLd * 2u;
+    const u32x4_t xdesc = make_desc(reinterpret_cast<const char*>(a.x) + (size_t)t * a.H * a.W * ldB, a.xBytes);
+    const u32x4_t wAdesc = make_desc(a.wA, a.wBytes), wBdesc = make_desc(a.wB, a.wBytes);
+    const u32x4_t bAdesc = make_desc(a.biasA, a.biasA ? 256u : 0u), bBdesc = make_desc(a.biasB, a.biasB ? 256u : 0u);
+
+    // ---- prologue DMA in the order of first use: biases, halo chunk 0, weights A0 | halo chunk 1, weights A1
+    dma16(bAdesc, (unsigned)(lane * 16), (unsigned)BIAS);
+    dma16(bBdesc, (unsigned)(lane * 16), (unsigned)(BIAS + 1024));
+    auto issue_halo = [&](int ch) {
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+            const int k = (wave * NH + i) % IN_INSTR;
+            const int R = k * 16 + lrow;
+            const int hr = R / WIN, c = R - hr * WIN;
+            const int hh = h0 - 2 + hr, ww = w0 - 2 + c;
+            const bool ok = (unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W;
+            const unsigned voff = ok ? (unsigned)(hh * a.W + ww) * ldB + (unsigned)(ch * 64) + (unsigned)((lchunk ^ ((c >> 2) & 3)) << 4) : FLAIR_OOB;
+            dma16(xdesc, voff, (unsigned)(ch * IN_IMG + k * 1024));
+        }
+    };
+    unsigned wlane[NWS];
+#pragma unroll
+    for (int i = 0; i < NWS; ++i) {
+        const int id = (wave * NWS + i) % WINSTR;
+        const int row = id * 16 + lrow, tap9 = row >> 6, co = row & 63;
+        wlane[i] = (unsigned)((co * 9 + tap9) * 64) * 2u + (unsigned)((lchunk ^ ((co >> 2) & 3)) << 4);
+    }
+    auto issue_w = [&](const u32x4_t& wd, int ch, int slot) {
+#pragma unroll
+        for (int i = 0; i < NWS; ++i) {
+            const int id = (wave * NWS + i) % WINSTR;
+            dma16(wd, (unsigned)(ch * 64) + wlane[i], (unsigned)(RING + slot * SLOT + id * 1024));
+        }
+    };
+    issue_halo(0);
+    issue_w(wAdesc, 0, 0);
+    issue_halo(1);
+    issue_w(wAdesc, 1, 1);
+
+    // ---- stage A: work item it = 32 intermediate pixels q = 32 it + lr (row-major in the 10 x 34 region) x 64 channels;
+    // wave w owns items w and w + 8 (items 8 .. 10: waves 0 .. 2)
+    const bool two = wave + NW < NITEM;                                 // wave-uniform
+    int q_[2], qr_[2], qc_[2];
+    unsigned boffA[2][3][2];
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii) {
+        int q = (wave + ii * NW) * 32 + lr;
+        if (q >= NPMID) q = NPMID - 1;                                  // tail lanes / idle second item recompute the last pixel (not stored)
+        q_[ii] = q; qr_[ii] = q / WMID; qc_[ii] = q - qr_[ii] * WMID;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                boffA[ii][kw][ks] = (unsigned)((qr_[ii] * WIN + qc_[ii] + kw) * 64 + (((2 * ks + lh) ^ (((qc_[ii] + kw) >> 2) & 3)) << 4));
+    }
+    unsigned aoff[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) aoff[ks] = (unsigned)(lr * 64 + (((2 * ks + lh) ^ ((lr >> 2) & 3)) << 4));
+
+    const float* sbias = reinterpret_cast<const float*>(smem + BIAS);
+    f32x16 accA[2][2];
+    auto init_from_bias = [&](f32x16 (&acc)[2], const float* b) {
+#pragma unroll
+        for (int cf = 0; cf < 2; ++cf)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 bq = *reinterpret_cast<const float4*>(b + cf * 32 + 8 * g + 4 * lh);
+                acc[cf][4 * g] = bq.x; acc[cf][4 * g + 1] = bq.y; acc[cf][4 * g + 2] = bq.z; acc[cf][4 * g + 3] = bq.w;
+            }
+    };
+    // one chunk of stage A: per tap one set of weight fragments serves both items of the wave
+    auto compute_A = [&](int slot, int ch) {
+        const char* wb = smem + RING + slot * SLOT;
+        const char* xb = smem + ch * IN_IMG;
+        uint4 fa[2][2][2], fb[2][2][2];      // [set][cout fragment | item][k-step]
+        auto load_tap = [&](int set, int tap9) {
+            const int kh = tap9 / 3, kw = tap9 % 3;
+#pragma unroll
+            for (int cf = 0; cf < 2; ++cf)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) fa[set][cf][ks] = *reinterpret_cast<const uint4*>(wb + tap9 * 4096 + cf * 2048 + aoff[ks]);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fb[set][0][ks] = *reinterpret_cast<const uint4*>(xb + kh * (WIN * 64) + boffA[0][kw][ks]);
+            if (two) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) fb[set][1][ks] = *reinterpret_cast<const uint4*>(xb + kh * (WIN * 64) + boffA[1][kw][ks]);
+            }
+        };
+        load_tap(0, 0);
+#pragma unroll
+        for (int tap9 = 0; tap9 < 9; ++tap9) {
+            const int set = tap9 & 1;
+            if (tap9 < 8) load_tap(set ^ 1, tap9 + 1);
+#pragma unroll
+            for (int cf = 0; cf < 2; ++cf)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    accA[0][cf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][cf][ks]), __builtin_bit_cast(bf16x8, fb[set][0][ks]), accA[0][cf], 0, 0, 0);
+            if (two) {
+#pragma unroll
+                for (int cf = 0; cf < 2; ++cf)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+                        accA[1][cf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][cf][ks]), __builtin_bit_cast(bf16x8, fb[set][1][ks]), accA[1][cf], 0, 0, 0);
+            }
+        }
+    };
+
+    // stage 0 (A, chunk 0): biases, halo chunk 0 and weights A0 have landed; halo chunk 1 and weights A1 (NH + NWS) stay in flight
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NH + NWS) : "memory");
+    __builtin_amdgcn_s_barrier();
+    init_from_bias(accA[0], sbias);
+    init_from_bias(accA[1], sbias);
+    compute_A(0, 0);
+    // stage 1 (A, chunk 1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                        // everybody is done with ring slot 0
+    issue_w(wBdesc, 0, 0);                               // weights B0 fly during this stage and the intermediate pass
+    compute_A(1, 1);
+    __builtin_amdgcn_s_barrier();                        // everybody is done with the input halo and ring slot 1
+    issue_w(wBdesc, 1, 1);
+
+    // ---- intermediate -> LDS over the halo: activation, zero outside the image, bf16; lane = pixel q, 8 consecutive channels per piece
+    {
+        const float slopeA = a.actA == FLAIR_ACT_NONE ? 1.f : a.actA == FLAIR_ACT_RELU ? 0.f : 0.1f;
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+            if (ii == 1 && !two) break;                  // wave-uniform
+            const int qraw = (wave + ii * NW) * 32 + lr;
+            const int hh = h0 - 1 + qr_[ii], ww = w0 - 1 + qc_[ii];
+            const bool inimg = (unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W;
+            const unsigned sw = (unsigned)((qc_[ii] >> 2) & 3);
+#pragma unroll
+            for (int cf = 0; cf < 2; ++cf)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const auto sw2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(accA[ii][cf][8 * jj + e]), __float_as_uint(accA[ii][cf][8 * jj + 4 + e]), false, false);
+                        v[e] = __uint_as_float(sw2[0]);
+                        v[4 + e] = __uint_as_float(sw2[1]);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = inimg ? fmaxf(v[e], v[e] * slopeA) : 0.f;
+                    alignas(16) E out[8];
+                    Vec16<E>::store(out, v);
+                    // channels cf * 32 + 16 jj + 8 lh .. + 7: chunk image cf, 16-byte piece 2 jj + lh of the pixel's 64-byte row
+                    if (qraw < NPMID)
+                        *reinterpret_cast<uint4*>(smem + cf * MID_IMG + q_[ii] * 64 + (((2 * jj + lh) ^ sw) << 4)) = *reinterpret_cast<const uint4*>(out);
+                }
+        }
+    }
+
+    // ---- stage B: wave = output row `wave` of the tile x 32 pixels x 64 channels
+    const long prow = ((long)t * a.H + h0 + wave) * a.W + w0;                 // first pixel of the wave's row
+    const unsigned yLdB = (unsigned)a.yLd * 2u, r0LdB = (unsigned)a.res0Ld * 2u, r1LdB = (unsigned)a.res1Ld * 2u;
+    const __amdgpu_buffer_rsrc_t yd = make_rsrc(reinterpret_cast<char*>(a.y) + prow * a.yLd * 2, (unsigned)a.W * yLdB);
+    const __amdgpu_buffer_rsrc_t r0d = make_rsrc(a.res0 ? reinterpret_cast<const char*>(a.res0) + prow * a.res0Ld * 2 : nullptr, a.res0 ? (unsigned)a.W * r0LdB : 0u);
+    const __amdgpu_buffer_rsrc_t r1d = make_rsrc(a.res1 ? reinterpret_cast<const char*>(a.res1) + prow * a.res1Ld * 2 : nullptr, a.res1 ? (unsigned)a.W * r1LdB : 0u);
+    // both residual inputs of the wave's pixels (16 bytes per (cout group, lane)): requested now, used in the epilogue.  Without a
+    // residual no load is issued (zero-sized resource + a uniform branch), so the counted waits below know how many are in flight.
+    uint4 r0v[4], r1v[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) r0v[g] = r1v[g] = make_uint4(0u, 0u, 0u, 0u);
+    const int nres = (a.res0 ? 4 : 0) + (a.res1 ? 4 : 0);                      // wave-uniform
+    if (a.res0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) r0v[g] = buf_load16(r0d, (unsigned)lr * r0LdB + (unsigned)(32 * g + 16 * lh));
+    }
+    if (a.res1) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) r1v[g] = buf_load16(r1d, (unsigned)lr * r1LdB + (unsigned)(32 * g + 16 * lh));
+    }
+    unsigned boffB[3][2];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            boffB[kw][ks] = (unsigned)((wave * WMID + kw + lr) * 64 + (((2 * ks + lh) ^ (((kw + lr) >> 2) & 3)) << 4));
+    f32x16 accB[2];
+    auto compute_B = [&](int slot, int ch) {
+        const char* wb = smem + RING + slot * SLOT;
+        const char* xb = smem + ch * MID_IMG;
+        uint4 fb[2][3][2], fa[2][2][2];
+        auto load_b = [&](int set, int kw) {
+#pragma unroll
+            for (int h = 0; h < 3; ++h)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) fb[set][h][ks] = *reinterpret_cast<const uint4*>(xb + h * (WMID * 64) + boffB[kw][ks]);
+        };
+        auto load_a = [&](int set, int kh, int kw) {
+#pragma unroll
+            for (int cf = 0; cf < 2; ++cf)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) fa[set][cf][ks] = *reinterpret_cast<const uint4*>(wb + (kh * 3 + kw) * 4096 + cf * 2048 + aoff[ks]);
+        };
+        load_b(0, 0);
+        load_a(0, 0, 0);
+#pragma unroll
+        for (int step = 0; step < 9; ++step) {
+            const int kq = step / 3, kh = step % 3;
+            const int nkq = (step + 1) / 3, nkh = (step + 1) % 3;
+            if (step < 8) {
+                if (nkh == 0) load_b(nkq & 1, nkq);
+                load_a((step + 1) & 1, nkh, nkq);
+            }
+#pragma unroll
+            for (int cf = 0; cf < 2; ++cf)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    accB[cf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[step & 1][cf][ks]), __builtin_bit_cast(bf16x8, fb[kq & 1][kh][ks]), accB[cf], 0, 0, 0);
+        }
+    };
+    // stage 2 (B, chunk 0): weights B0 landed (younger: weights B1 and the residual loads), the intermediate is written
+    if (nres == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NWS) : "memory");
+    else if (nres == 4) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NWS + 4) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NWS + 8) : "memory");
+    __builtin_amdgcn_s_barrier();
+    init_from_bias(accB, sbias + 256);
+    compute_B(0, 0);
+    // stage 3 (B, chunk 1)
+    if (nres == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (nres == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    compute_B(1, 1);
+
+    // ---- epilogue from the accumulators: activation, + res0 + res1, scale, 16-byte stores
+    const float slopeB = a.actB == FLAIR_ACT_NONE ? 1.f : a.actB == FLAIR_ACT_RELU ? 0.f : 0.1f;
+    const float scale = a.outScale;
+#pragma unroll
+    for (int cf = 0; cf < 2; ++cf)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int g = 2 * cf + jj;                   // couts 16 g + 8 lh .. + 7
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const auto sw2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(accB[cf][8 * jj + e]), __float_as_uint(accB[cf][8 * jj + 4 + e]), false, false);
+                v[e] = __uint_as_float(sw2[0]);
+                v[4 + e] = __uint_as_float(sw2[1]);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], v[e] * slopeB);
+            float r[8];
+            Vec16<E>::load(reinterpret_cast<const E*>(&r0v[g]), r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += r[e];
+            Vec16<E>::load(reinterpret_cast<const E*>(&r1v[g]), r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (v[e] + r[e]) * scale;
+            alignas(16) E out[8];
+            Vec16<E>::store(out, v);
+            const uint4 ov = *reinterpret_cast<const uint4*>(out);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{ov.x, ov.y, ov.z, ov.w}, yd, (int)((unsigned)lr * yLdB + (unsigned)(32 * g + 16 * lh)), 0, 0);
+        }
+}
+
+int launch_pair(const ChainArgs& c, hipStream_t s) {
+    PairArgs a;
+    a.x = c.x[0]; a.xLd = c.segLd[0]; a.xBytes = c.segBytes[0];
+    a.wA = c.wA; a.wB = c.wB; a.wBytes = 64u * 9u * 64u * 2u;
+    a.biasA = c.biasA; a.biasB = c.biasB; a.actA = c.actA; a.actB = c.actB; a.outScale = c.outScale;
+    a.res0 = c.res0; a.res1 = c.res1; a.res0Ld = c.res0Ld; a.res1Ld = c.res1Ld;
+    a.y = c.y; a.yLd = c.yLd; a.T = c.T; a.H = c.H; a.W = c.W;
+    constexpr size_t lds = 2 * 27 * 1024 + 2 * 36 * 1024 + 2048;
+    static LdsAttrOnce attr;
+    const hipError_t e = flair_max_lds_once(attr, reinterpret_cast<const void*>(&conv_pair_kernel));
+    FLAIR_CHECK(e == hipSuccess, "flair_conv_chain: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(conv_pair_kernel, dim3(c.T * (c.H / 8) * (c.W / 32)), dim3(512), lds, s, a);
+    FLAIR_LAUNCH_CHECK();
+    return FLAIR_OK;
+}
+
 template <typename E, int C, int TH, int TW, bool HASA>
 int launch_chain(const ChainArgs& a, hipStream_t s) {
     constexpr int BKE = MmaC<E>::BKE;
@@ -925,6 +1247,17 @@ extern "C" int flair_conv_chain(const flair_chain_params* p, const void* const* 
             (p->y_ld * 2) % 16 == 0 && p->CoutB % 8 == 0 &&
             (unsigned long long)p->H * p->W * p->y_ld * 2 < 0x40000000ull)
             return launch_resident(a, stream);
+    }
+    // round 4: the c = 64 pair on LDS-DMA staging (conv_pair_kernel; FLAIR_CONV_PAIR=0: the register-staged form above).
+    // Same box: fused-chain family 11.57 / 11.56 -> 10.59 / 10.55 ms per step (310 launches, 18.7 -> 15.5 us), step 72.84 / 72.76 -> 71.58 / 71.60 ms.
+    {
+        static const bool usePair = !(getenv("FLAIR_CONV_PAIR") && atoi(getenv("FLAIR_CONV_PAIR")) == 0);
+        auto lin = [](int c) { return c == FLAIR_ACT_NONE || c == FLAIR_ACT_RELU || c == FLAIR_ACT_LRELU01; };
+        if (usePair && hasA && p->dtype == FLAIR_BF16 && p->C == 64 && p->nseg == 1 && cin == 64 && p->CoutB == 64 && p->W % 32 == 0 &&
+            p->H % 8 == 0 && lin(p->actA) && lin(p->actB) && (unsigned long long)p->H * p->W * p->y_ld * 2 < 0x40000000ull &&
+            (!res0 || (unsigned long long)p->H * p->W * p->res_ld[0] * 2 < 0x40000000ull) &&
+            (!res1 || (unsigned long long)p->H * p->W * p->res_ld[1] * 2 < 0x40000000ull))
+            return launch_pair(a, stream);
     }
     // partial tiles in H are masked (hh < H); tile widths (32 or 8) divide W by the check above
     if (p->dtype == FLAIR_BF16)

@@ -134,6 +134,9 @@ def test_conv_frame_bias(dev, dtype, case):
     (16, 64, 64, [64], 64, 64, 1, 0, 1),               # clip-level (reconstruction trunk), >= 192 wide tiles
     (1, 250, 256, [64, 64], 64, 64, 2, 0, 1),          # partial last row of tiles at 256 wide
     (1, 24, 16, None, 64, 72, 0, 2, 1),                # CoutB not a multiple of 64
+    (2, 16, 64, [64], 64, 64, 2, 0, 2),                # the c = 64 pair with both residual inputs, two frames
+    (1, 8, 32, [64], 64, 64, 0, 1, 1),                 # one tile: every border of the halo and of the intermediate is padding
+    (1, 256, 256, [64], 64, 64, 1, 2, 2),              # ResidualBlockNoBN at the 256^2 level
 ])
 def test_conv_chain(dev, dtype, case):
     """Two fused 3x3 convolutions (flair_conv_chain) against two plain torch convolutions, the intermediate
