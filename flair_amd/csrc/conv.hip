@@ -1611,6 +1611,235 @@ int launch_dma(const ConvArgs& a0, hipStream_t s) {
     return FLAIR_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// One-tile 3x3 convolution with a THREE-deep weight ring (round 4): the per-frame convolutions of the 256^2 level (Cout <= 64, one
+// 8 x 32 tile per workgroup, 4-7 K chunks).  conv3x3_dma_kernel<8, 1, 2> stages halo + weights of a chunk together in two 58 KB stages:
+// chunk n + 1 is requested when chunk n starts to be multiplied and must have landed 2 304 MFMA cycles later -- it has not (measured
+// ~2.2 us per chunk against 1.15 us of matrix work).  Three such stages do not fit the LDS; here the 36 KB weight images go through a
+// ring of three (requested TWO chunks ahead) and the 22 KB halo images through a ring of two, 152 KB together, every wave issuing
+// the same number of DMA instructions per phase so that one immediate vmcnt serves all waves (the recipe of conv_resident_kernel /
+// conv_pair_kernel in chain.hip).  Epilogue from the accumulators; both residual inputs are requested at the head of the last chunk.
+// bf16, stride 1, KT = 1, W % 32 == 0, H % 8 == 0, segments multiples of 32 channels, activations none / ReLU / LeakyReLU(0.1 | 0.2).
+template <bool HALO3>       // false: halo ring of two + weight ring of three; true: halo ring of THREE + weight ring of two (138 KB)
+__global__ __launch_bounds__(512, 2) void conv_frame_kernel(ConvArgs a) {
+    prefetch_kernargs<sizeof(ConvArgs)>();
+    using E = bf16_t;
+    constexpr int NW = 8, HWP = 34;
+    constexpr int HINSTR = 22, HIMG = HINSTR * 1024, WINSTR = 36, SLOT = WINSTR * 1024;
+    constexpr int HR = HALO3 ? 3 : 2, WR = HALO3 ? 2 : 3;
+    constexpr int RING = HR * HIMG, BIAS = RING + WR * SLOT;
+    constexpr int NH = (HINSTR + NW - 1) / NW, NWS = (WINSTR + NW - 1) / NW;   // 3, 5
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int lrow = lane >> 2, lchunk = lane & 3;
+    const int tilesW = a.W / 32, perFrame = tilesW * (a.H / 8);
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int t = bid / perFrame, tile = bid - t * perFrame;
+    const int h0 = (tile / tilesW) * 8, w0 = (tile % tilesW) * 32;
+    const int nS = a.CinTot / 32;
+
+    const u32x4_t wdesc = make_desc(a.w, a.wBytes);
+    const u32x4_t bdesc = make_desc(a.bias, a.bias ? (unsigned)a.Cout * 4u : 0u);
+    dma16(bdesc, (unsigned)(lane * 16), (unsigned)BIAS);
+    // halo pixel of each of this wave's halo instructions (frame-relative pixel index, or "outside") and its swizzled 16-byte piece
+    unsigned hpix[NH], hpiece[NH];
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+        const int k = (wave * NH + i) % HINSTR;
+        const int R = k * 16 + lrow;
+        const int hr = R / HWP, c = R - hr * HWP;
+        const int hh = h0 - 1 + hr, ww = w0 - 1 + c;
+        const bool ok = R < 10 * HWP && (unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W;
+        hpix[i] = ok ? (unsigned)(hh * a.W + ww) : 0xffffffffu;
+        hpiece[i] = (unsigned)((lchunk ^ ((c >> 2) & 3)) << 4);
+    }
+    unsigned wlane[NWS];
+#pragma unroll
+    for (int i = 0; i < NWS; ++i) {
+        const int id = (wave * NWS + i) % WINSTR;
+        const int row = id * 16 + lrow, tap9 = row >> 6, co = row & 63;
+        wlane[i] = co < a.Cout ? (unsigned)((co * 9 + tap9) * a.CinTot) * 2u + (unsigned)((lchunk ^ ((co >> 2) & 3)) << 4) : FLAIR_OOB;
+    }
+    // K walk of the halo issues over (segment, 32-channel chunk of the segment)
+    int hseg = 0, hcb = 0;
+    auto issue_halo = [&](int slot) {
+        const unsigned ld = (unsigned)a.segLd[hseg] * 2u;
+        const u32x4_t xdesc = make_desc(reinterpret_cast<const char*>(a.x[hseg]) + (size_t)t * a.H * a.W * ld, a.segBytes[hseg]);
+        const unsigned cofs = (unsigned)(hcb * 64);
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+            const int k = (wave * NH + i) % HINSTR;
+            dma16(xdesc, hpix[i] == 0xffffffffu ? FLAIR_OOB : hpix[i] * ld + cofs + hpiece[i], (unsigned)(slot * HIMG + k * 1024));
+        }
+        if (++hcb * 32 >= a.segC[hseg]) {
+            hcb = 0;
+            ++hseg;
+        }
+    };
+    auto issue_w = [&](int s_) {
+#pragma unroll
+        for (int i = 0; i < NWS; ++i) {
+            const int id = (wave * NWS + i) % WINSTR;
+            dma16(wdesc, wlane[i] == FLAIR_OOB ? FLAIR_OOB : wlane[i] + (unsigned)(s_ * 64), (unsigned)(RING + (s_ % WR) * SLOT + id * 1024));
+        }
+    };
+    issue_halo(0);
+    issue_w(0);
+    if (nS > 1) {
+        issue_halo(1);
+        issue_w(1);
+    }
+    if (HALO3 && nS > 2) issue_halo(2);
+
+    unsigned aoff[2], boff[3][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        aoff[ks] = (unsigned)(lr * 64 + (((2 * ks + lh) ^ ((lr >> 2) & 3)) << 4));
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+            boff[kw][ks] = (unsigned)((wave * HWP + kw + lr) * 64 + (((2 * ks + lh) ^ (((kw + lr) >> 2) & 3)) << 4));
+    }
+    f32x16 acc[2];
+    auto compute = [&](int wslot, int hslot) {
+        const char* wb = smem + RING + wslot * SLOT;
+        const char* xb = smem + hslot * HIMG;
+        uint4 fb[2][3][2], fa[2][2][2];
+        auto load_b = [&](int set, int kw) {
+#pragma unroll
+            for (int h = 0; h < 3; ++h)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) fb[set][h][ks] = *reinterpret_cast<const uint4*>(xb + h * (HWP * 64) + boff[kw][ks]);
+        };
+        auto load_a = [&](int set, int kh, int kw) {
+#pragma unroll
+            for (int cf = 0; cf < 2; ++cf)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) fa[set][cf][ks] = *reinterpret_cast<const uint4*>(wb + (kh * 3 + kw) * 4096 + cf * 2048 + aoff[ks]);
+        };
+        load_b(0, 0);
+        load_a(0, 0, 0);
+#pragma unroll
+        for (int step = 0; step < 9; ++step) {
+            const int kq = step / 3, kh = step % 3;
+            const int nkq = (step + 1) / 3, nkh = (step + 1) % 3;
+            if (step < 8) {
+                if (nkh == 0) load_b(nkq & 1, nkq);
+                load_a((step + 1) & 1, nkh, nkq);
+            }
+#pragma unroll
+            for (int cf = 0; cf < 2; ++cf)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    acc[cf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[step & 1][cf][ks]), __builtin_bit_cast(bf16x8, fb[kq & 1][kh][ks]), acc[cf], 0, 0, 0);
+        }
+    };
+
+    const long prow = ((long)t * a.H + h0 + wave) * a.W + w0;
+    const unsigned yLdB = (unsigned)a.yLd * 2u, r0LdB = (unsigned)a.res0Ld * 2u, r1LdB = (unsigned)a.res1Ld * 2u;
+    const __amdgpu_buffer_rsrc_t yd = make_rsrc(reinterpret_cast<char*>(a.y) + prow * a.yLd * 2, (unsigned)a.W * yLdB);
+    const __amdgpu_buffer_rsrc_t r0d = make_rsrc(a.res0 ? reinterpret_cast<const char*>(a.res0) + prow * a.res0Ld * 2 : nullptr, a.res0 ? (unsigned)a.W * r0LdB : 0u);
+    const __amdgpu_buffer_rsrc_t r1d = make_rsrc(a.res1 ? reinterpret_cast<const char*>(a.res1) + prow * a.res1Ld * 2 : nullptr, a.res1 ? (unsigned)a.W * r1LdB : 0u);
+    uint4 r0v[4], r1v[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) r0v[g] = r1v[g] = make_uint4(0u, 0u, 0u, 0u);
+
+    for (int s_ = 0; s_ < nS; ++s_) {
+        // halo s_ and weights s_ have landed; younger in flight: at s_ = 0 halo 1 + weights 1 (+ halo 2), later the weights of s_ + 1
+        // (HALO3: the halo of s_ + 1, issued behind the weights of s_)
+        if constexpr (HALO3) {
+            if (s_ + 1 >= nS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (s_ == 0 && nS > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NH + NWS) : "memory");
+            else if (s_ == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NH + NWS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NH) : "memory");      // the halo of s_ + 1 (prologue / behind the weights of s_)
+        } else {
+            if (s_ + 1 >= nS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (s_ == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NH + NWS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWS) : "memory");
+        }
+        __builtin_amdgcn_s_barrier();                    // ... for everybody; everybody is done with chunk s_ - 1
+        if (s_ == 0) {
+            const float* sb = reinterpret_cast<const float*>(smem + BIAS);
+#pragma unroll
+            for (int cf = 0; cf < 2; ++cf)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 bq = *reinterpret_cast<const float4*>(sb + cf * 32 + 8 * g + 4 * lh);
+                    acc[cf][4 * g] = bq.x; acc[cf][4 * g + 1] = bq.y; acc[cf][4 * g + 2] = bq.z; acc[cf][4 * g + 3] = bq.w;
+                }
+        }
+        if constexpr (HALO3) {
+            if (s_ >= 1 && s_ + 1 < nS) issue_w(s_ + 1);                   // weight slot of chunk s_ - 1
+            if (s_ >= 1 && s_ + 2 < nS) issue_halo((s_ + 2) % 3);          // halo slot of chunk s_ - 1
+        } else {
+            if (s_ >= 1 && s_ + 1 < nS) issue_halo((s_ + 1) & 1);          // halo slot of chunk s_ - 1
+            if (s_ + 2 < nS) issue_w(s_ + 2);                              // weight slot of chunk s_ - 1
+        }
+        if (s_ + 1 == nS) {                                            // last chunk: the residual inputs, used in the epilogue
+            if (a.res0) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) r0v[g] = buf_load16(r0d, 16 * g + 8 * lh < a.Cout ? (unsigned)lr * r0LdB + (unsigned)(32 * g + 16 * lh) : FLAIR_OOB);
+            }
+            if (a.res1) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) r1v[g] = buf_load16(r1d, 16 * g + 8 * lh < a.Cout ? (unsigned)lr * r1LdB + (unsigned)(32 * g + 16 * lh) : FLAIR_OOB);
+            }
+        }
+        compute(s_ % WR, s_ % HR);
+    }
+
+    const float slope = a.act == FLAIR_ACT_NONE ? 1.f : a.act == FLAIR_ACT_RELU ? 0.f : a.act == FLAIR_ACT_LRELU01 ? 0.1f : 0.2f;
+    const float scale = a.outScale;
+#pragma unroll
+    for (int cf = 0; cf < 2; ++cf)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int g = 2 * cf + jj;                   // couts 16 g + 8 lh .. + 7
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const auto sw2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[cf][8 * jj + e]), __float_as_uint(acc[cf][8 * jj + 4 + e]), false, false);
+                v[e] = __uint_as_float(sw2[0]);
+                v[4 + e] = __uint_as_float(sw2[1]);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], v[e] * slope);
+            float r[8];
+            Vec16<E>::load(reinterpret_cast<const E*>(&r0v[g]), r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += r[e];
+            Vec16<E>::load(reinterpret_cast<const E*>(&r1v[g]), r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (v[e] + r[e]) * scale;
+            alignas(16) E out[8];
+            Vec16<E>::store(out, v);
+            const uint4 ov = *reinterpret_cast<const uint4*>(out);
+            const unsigned yo = 16 * g + 8 * lh < a.Cout ? (unsigned)lr * yLdB + (unsigned)(32 * g + 16 * lh) : FLAIR_OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{ov.x, ov.y, ov.z, ov.w}, yd, (int)yo, 0, 0);
+        }
+}
+
+static bool frame_kernel_ok(const ConvArgs& a) {
+    if (a.esz != 2 || a.KT != 1 || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.fbias || a.Cout > 64 || a.Cout % 8 || a.W % 32 || a.H % 8) return false;
+    if (!(a.act == FLAIR_ACT_NONE || a.act == FLAIR_ACT_RELU || a.act == FLAIR_ACT_LRELU01 || a.act == FLAIR_ACT_LRELU02)) return false;
+    if (a.tapShift || a.reflect || a.CinTot % 32 || a.CinTot < 32) return false;
+    for (int i = 0; i < a.nseg; ++i)
+        if (a.segC[i] % 32) return false;
+    return true;
+}
+
+template <bool HALO3>
+static int launch_frame(const ConvArgs& a, hipStream_t s) {
+    constexpr size_t lds = (HALO3 ? 3 * 22 + 2 * 36 : 2 * 22 + 3 * 36) * 1024 + 1024;
+    static LdsAttrOnce attr;
+    const hipError_t e = flair_max_lds_once(attr, reinterpret_cast<const void*>(&conv_frame_kernel<HALO3>));
+    FLAIR_CHECK(e == hipSuccess, "flair_conv_nhwc: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(conv_frame_kernel<HALO3>, dim3(a.T * (a.H / 8) * (a.W / 32)), dim3(512), lds, s, a);
+    FLAIR_LAUNCH_CHECK();
+    return FLAIR_OK;
+}
+
 // TC x TP block tile (couts x pixels), 4 waves arranged WC x WP.
 // PD = K steps whose operands are in flight in registers ahead of the step being multiplied.  One K step is 8 MFMAs per wave
 // (64 x 64 tile: 2), far less than one round trip to the L2 / HBM, so with PD = 1 (rounds 1-2) every step lasted one load
@@ -2009,7 +2238,15 @@ int dispatch(const ConvArgs& a0, hipStream_t s) {
             static const int rpw4 = getenv("FLAIR_DMA_RPW4") ? atoi(getenv("FLAIR_DMA_RPW4")) : 0;
             return rpw4 ? launch_dma<4, 4, 2>(a, s) : launch_dma<8, 2, 2>(a, s);
         }
-        case 9: return launch_dma<8, 1, 2>(a, s);
+        case 9: {
+            // conv_frame_kernel for the shapes it takes (FLAIR_CONV_FRAME: 2 (default) halo ring of three + weight ring of two, 1 halo ring of
+            // two + weight ring of three, 0 conv3x3_dma_kernel<8, 1, 2>).  Same box: per-frame family 19.59 / 19.55 -> 19.03 / 18.95 (1) ->
+            // 19.03 / 19.09 (2) ms per step, step 70.89 / 70.92 -> 70.63 / 70.65 -> 70.54 / 70.57 ms.
+            static const int frame = getenv("FLAIR_CONV_FRAME") ? atoi(getenv("FLAIR_CONV_FRAME")) : 2;
+            if (frame == 1 && frame_kernel_ok(a)) return launch_frame<false>(a, s);
+            if (frame == 2 && frame_kernel_ok(a)) return launch_frame<true>(a, s);
+            return launch_dma<8, 1, 2>(a, s);
+        }
         case 10: return launch_dma<4, 1, 3>(a, s);
         case 11: return launch_dma<8, 1, 3, 2>(a, s);
         default: return launch_halo<E, 2, 1, 1>(a, s);
