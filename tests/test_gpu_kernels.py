@@ -45,6 +45,11 @@ def _ops():
     (4, 64, 64, [64], 128, (3, 3, 3), 0, 1),
     (1, 250, 256, [64], 64, (1, 3, 3), 3, 1),       # last row of tiles hangs over the image
     (1, 125, 128, [32], 128, (1, 3, 3), 0, 0),
+    # conv_frame_kernel (round 4: one 256-tile round, Cout <= 64): one / two / seven K chunks, padded couts, each residual count
+    (1, 256, 256, [32], 64, (1, 3, 3), 0, 1),
+    (1, 256, 256, [64], 24, (1, 3, 3), 1, 1),
+    (1, 256, 256, [64, 64, 64, 32], 64, (1, 3, 3), 2, 0),
+    (4, 128, 128, [32, 32], 40, (1, 3, 3), 1, 2),
     # persistent LDS-DMA kernel (bf16; f32 takes the halo kernel): >= 192 tiles of 16 rows x 32 px x 64 couts --
     # one tile per workgroup, 2 and 1.5 tiles per workgroup, three temporal taps with clip edges, 432 couts, 4 segments
     (4, 128, 128, [64], 128, (1, 3, 3), 0, 1),
