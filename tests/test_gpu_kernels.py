@@ -45,6 +45,11 @@ def _ops():
     (4, 64, 64, [64], 128, (3, 3, 3), 0, 1),
     (1, 250, 256, [64], 64, (1, 3, 3), 3, 1),       # last row of tiles hangs over the image
     (1, 125, 128, [32], 128, (1, 3, 3), 0, 0),
+    # one-round launches of 4-row tiles (the 128^2 level, c = 128): the K-split kernel / conv_frame_ks_kernel
+    (1, 128, 128, [128], 128, (1, 3, 3), 2, 1),
+    (1, 128, 128, [128, 128, 128, 32], 128, (1, 3, 3), 2, 0),
+    (1, 128, 128, [64], 72, (1, 3, 3), 1, 2),
+    (2, 64, 128, [32], 128, (1, 3, 3), 0, 0),
     # conv_frame_kernel (round 4: one 256-tile round, Cout <= 64): one / two / seven K chunks, padded couts, each residual count
     (1, 256, 256, [32], 64, (1, 3, 3), 0, 1),
     (1, 256, 256, [64], 24, (1, 3, 3), 1, 1),
